@@ -1,0 +1,50 @@
+"""Shared test helpers: golden-fixture loading and fixture -> oracle Problem mapping."""
+import glob
+import os
+
+import numpy as np
+
+from oracle import gpe_oracle as go
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_fx(name):
+    return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
+
+
+def refine_names():
+    return sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "fx_refine_*.npz")))
+
+
+def nb_names():
+    return sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "fx_nb_*.npz")))
+
+
+def problem_from_refine(fx) -> go.Problem:
+    """refine/harmonic_pinn_simulation.py flavour: ShiftedTanh, -u'' + x^2 u + gamma u^p, 10*bc + 20*norm."""
+    return go.Problem(layers=[int(v) for v in fx["layers"]], activation=1, kinetic_coeff=1.0,
+                      potential=go.POT_HARMONIC, pot_scale=1.0, gamma=float(fx["gamma"]), p=int(fx["p"]),
+                      base_mode=int(fx["mode"]), base_deriv=0,
+                      perturb_scale=float(fx["perturb_const"]) / float(fx["normal_const"]), bc_nn_scale=1.0,
+                      w_bc=10.0, w_norm=20.0, w_sym=0.0, dx=float(fx["dx"]))
+
+
+def problem_from_nb(fx) -> go.Problem:
+    """root-notebook flavour: tanh, -1/2 u'' + 1/2 x^2 u + gamma u^p, 10*bc + 20*norm + 5*sym."""
+    mode = int(fx["mode"])
+    return go.Problem(layers=[int(v) for v in fx["layers"]], activation=0, kinetic_coeff=0.5,
+                      potential=go.POT_HARMONIC, pot_scale=0.5, gamma=float(fx["gamma"]), p=int(fx["p"]),
+                      base_mode=mode, base_deriv=1, perturb_scale=1.0, bc_nn_scale=1.0,
+                      w_bc=10.0, w_norm=20.0, w_sym=5.0, sym_sign=(-1.0 if mode % 2 == 1 else 1.0),
+                      dx=float(fx["dx"]))
+
+
+def bc_points(fx):
+    return np.array([[float(fx["lb"])], [float(fx["ub"])]], dtype=np.float64)
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-300))

@@ -1,0 +1,116 @@
+"""Pin the CPU oracle (oracle/gpe_oracle.py, oracle/torch_ref.py) against golden vectors produced by the
+imported reference (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import gpe_oracle as go
+from tests import helpers as H
+
+
+@pytest.mark.parametrize("name", H.refine_names())
+def test_refine_oplevel(name):
+    fx = H.load_fx(name)
+    pb = H.problem_from_refine(fx)
+    x = fx["x"].astype(np.float64)
+    flat = fx["flat0"].astype(np.float64)
+    params = go.unflatten(flat, pb.layers)
+    out, _ = go.mlp_forward(params, x, pb.activation)
+    assert H.rel_err(out[0], fx["nn_out"]) < 1e-5                       # forward (a3)
+    h = go.head_pde(pb, x, out)
+    U = h["U"]
+    assert H.rel_err(U[0], fx["u"]) < 2e-6                              # a5
+    assert H.rel_err(U[1], fx["u_x"]) < 5e-6                            # K2: autograd d/dx
+    assert H.rel_err(U[2], fx["u_xx"]) < 2e-5                           # K3: autograd d2/dx2
+    assert H.rel_err(h["V"][:, None], fx["V"]) < 1e-6                   # a6
+    sc, grad, res = go.full_loss_and_grad(pb, flat, x, H.bc_points(fx))
+    assert abs(sc["mu"] - float(fx["lam"])) < 2e-5 * max(1.0, abs(float(fx["lam"])))   # K6
+    assert H.rel_err(res["residual"], fx["residual"]) < 1e-4            # K7 (residual is a difference of O(1) terms)
+    assert abs(sc["pde"] - float(fx["pde_loss"])) < 2e-4 * max(1e-3, float(fx["pde_loss"]))
+    assert abs(sc["bc"] - float(fx["bc_loss"])) < 1e-5 * max(1e-6, float(fx["bc_loss"])) + 1e-12
+    assert abs(sc["norm"] - float(fx["norm_loss"])) < 1e-4 * max(1e-3, float(fx["norm_loss"]))
+    assert abs(sc["loss"] - float(fx["total"])) < 1e-4 * max(1e-3, float(fx["total"]))
+    # K12: d total / d theta (reference: autograd through the double-backward graph, fp32)
+    assert H.rel_err(grad, fx["grad0"]) < 2e-4
+
+
+@pytest.mark.parametrize("name", H.nb_names())
+def test_notebook_oplevel(name):
+    fx = H.load_fx(name)
+    pb = H.problem_from_nb(fx)
+    x = fx["x"].astype(np.float64)
+    flat = fx["flat0"].astype(np.float64)
+    sc, grad, res = go.full_loss_and_grad(pb, flat, x, H.bc_points(fx))
+    assert H.rel_err(res["psi"], fx["u"]) < 2e-6
+    assert abs(sc["mu"] - float(fx["lam"])) < 5e-5 * max(1.0, abs(float(fx["lam"])))
+    assert H.rel_err(res["residual"], fx["residual"]) < 2e-4
+    assert abs(sc["pde"] - float(fx["pde_loss"])) < 5e-4 * float(fx["pde_loss"])
+    assert abs(sc["sym"] - float(fx["sym_loss"])) < 1e-4 * max(1e-6, float(fx["sym_loss"]))
+    assert abs(sc["loss"] - float(fx["total"])) < 2e-4 * float(fx["total"])
+    assert H.rel_err(grad, fx["grad0"]) < 5e-4
+
+
+@pytest.mark.parametrize("name", ["fx_refine_m0_g0_64x3.npz", "fx_refine_m0_g50_64x3.npz", "fx_refine_m2_g10_32x4.npz"])
+def test_refine_trace_fp32(name):
+    """(loss, mu, lr) trace of the reference loop body (Adam + clip + cosine(loss) scheduler, quirk Q4)."""
+    fx = H.load_fx(name)
+    pb = H.problem_from_refine(fx)
+    st = go.OptState(lr0=1e-3, sched=go.SCHED_COSINE_LOSS)
+    n = 25
+    flat, trace = go.train_steps(pb, st, fx["flat0"], fx["x"], n, x_bc=H.bc_points(fx))
+    loss = np.array([t["loss"] for t in trace]); mu = np.array([t["mu"] for t in trace])
+    lr = np.array([t["lr"] for t in trace]); gn = np.array([t["grad_norm"] for t in trace])
+    np.testing.assert_allclose(lr, fx["trace_lr"][:n], rtol=2e-3, atol=1e-9)
+    np.testing.assert_allclose(loss[:10], fx["trace_loss"][:10], rtol=2e-3)
+    np.testing.assert_allclose(mu[:10], fx["trace_mu"][:10], rtol=5e-4)
+    np.testing.assert_allclose(gn[:5], fx["trace_gnorm"][:5], rtol=2e-3)
+    np.testing.assert_allclose(loss, fx["trace_loss"][:n], rtol=5e-2)
+    np.testing.assert_allclose(mu, fx["trace_mu"][:n], rtol=5e-3)
+    # params after 1..3 optimiser steps (fp32 Adam; sign(g)-like first step is sensitive where g~0)
+    f1, _ = go.train_steps(pb, go.OptState(lr0=1e-3, sched=go.SCHED_COSINE_LOSS), fx["flat0"], fx["x"], 1,
+                           x_bc=H.bc_points(fx))
+    d = np.abs(f1 - fx["flat_after_1"])
+    assert np.quantile(d, 0.99) < 2e-5 and d.max() <= 2.1e-3
+
+
+@pytest.mark.parametrize("name", ["fx_nb_m0_g1_p3_32x4.npz", "fx_nb_m0_g1_p2_64x3.npz"])
+def test_notebook_trace_fp32(name):
+    fx = H.load_fx(name)
+    pb = H.problem_from_nb(fx)
+    st = go.OptState(lr0=1e-3, sched=go.SCHED_PLATEAU)
+    n = 20
+    flat, trace = go.train_steps(pb, st, fx["flat0"], fx["x"], n, x_bc=H.bc_points(fx))
+    loss = np.array([t["loss"] for t in trace]); mu = np.array([t["mu"] for t in trace])
+    np.testing.assert_allclose(loss[:8], fx["trace_loss"][:8], rtol=3e-3)
+    np.testing.assert_allclose(mu[:8], fx["trace_mu"][:8], rtol=2e-3)
+    np.testing.assert_allclose(loss, fx["trace_loss"][:n], rtol=8e-2)
+
+
+def test_cosine_loss_schedule_closed_form():
+    fx = H.load_fx("fx_cosine_loss_lr.npz")
+    # the reference passes an fp32 loss tensor as the epoch, so T_cur is fp32 arithmetic there
+    got = np.array([go.cosine_lr_from_loss(float(np.float32(L)), 1e-3, 200.0, 2.0, 1e-6) for L in fx["loss"]])
+    np.testing.assert_allclose(got, fx["lr"], rtol=5e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", H.refine_names())
+def test_eval_density_refine(name):
+    fx = H.load_fx(name)
+    pb = H.problem_from_refine(fx)
+    xt = fx["eval_x"].astype(np.float64)
+    u, dens = go.eval_density(pb, fx["flat_final"].astype(np.float64), xt, float(xt[1, 0] - xt[0, 0]),
+                              abs_mode0=(int(fx["mode"]) == 0))
+    assert H.rel_err(u[:, 0], fx["eval_u"]) < 5e-5   # reference evaluates in fp32
+
+
+def test_eval_density_notebook():
+    fx = H.load_fx("fx_nb_m0_g1_p3_32x4.npz")
+    pb = H.problem_from_nb(fx)
+    xt = fx["eval_x"].astype(np.float64)
+    u, dens = go.eval_density(pb, fx["flat_final"].astype(np.float64), xt, float(xt[1, 0] - xt[0, 0]))
+    assert H.rel_err(dens, fx["eval_density"]) < 1e-4
+
+
+def test_q1_documented():
+    """The 2D reference residual broadcasts to [N,N] (quirk Q1) -- the build follows the intended [N,1] formula."""
+    fx = H.load_fx("fx_q1_2d_shape.npz")
+    assert tuple(fx["residual_shape"]) == (7, 7)
