@@ -1,0 +1,167 @@
+// gpe_common.h -- structs and device math shared by the generic and fused kernel sets (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/gpe_hip.h"
+
+#define GPE_DEV __device__ __forceinline__
+
+// Network description passed by value to kernels.  Linear map j: width[j] -> width[j+1], j = 0..n_lin-1.
+struct NetDesc {
+    int n_lin;                       // number of nn.Linear
+    int dim;                         // width[0]
+    int n_out;                       // width[n_lin]
+    float shift;                     // 0 (tanh) or 1 (tanh+1)
+    int width[GPE_MAX_LAYERS];
+    int offW[GPE_MAX_LAYERS];        // offsets into the flat (torch-order) parameter vector
+    int offB[GPE_MAX_LAYERS];
+    int n_params;
+};
+
+// Physics of the head, passed by value.
+struct Phys {
+    int dim, n_out, complex_psi;
+    float kin;                       // kinetic_coeff
+    int potential;
+    float pot_scale, omega[3], pot_a, pot_v0, pot_k;
+    float omega_rot;
+    float gamma;
+    int p, abs_power;
+    int base_mode, base_deriv;
+    float perturb_scale, bc_nn_scale;
+    float w_pde, w_bc, w_norm, w_sym, w_orth, sym_sign;
+    float dx;
+    double n_global;                 // N of the means
+    float inv_world;                 // 1/world_size: scales the replicated boundary batch
+    int n_orth;
+};
+
+// Indices into the double "sums" exchange buffer (all-reduced over ranks between phase 1 and 2).
+enum { S_NUM = 0, S_DEN = 1, S_SYM = 2, S_ORTH0 = 3, /* ..S_ORTH0+3 */ S_COUNT = 8 };
+// Local (replicated, never exchanged) double scalars.
+enum { LS_BC_SE2 = 0, LS_BC_CNT = 1, LS_COUNT = 4 };
+// Tail of the float gradient exchange buffer.
+enum { GT_SUM_R2 = 0, GT_COUNT = 4 };
+
+// Optimiser / scheduler state living on the device (one struct; updated by k_update).
+struct OptDev {
+    double lr;            // lr used by the NEXT step
+    double lr0;
+    double best;          // plateau: best loss
+    int num_bad;
+    int nonfinite;        // sticky flag: a non-finite loss/grad was seen, updates were skipped
+    long long step;       // optimiser steps taken
+};
+
+struct OptCfg {
+    float beta1, beta2, eps, clip_norm;
+    int sched;
+    float T_0, T_mult, eta_min;
+    float factor; int patience; float min_lr, threshold;
+};
+
+// ------------------------------------------------------------------------------------------------
+// tanh: odd polynomial for |x| < 0.25, 1 - 2/(exp(2|x|)+1) otherwise.  abs error ~1e-7.
+// Shared by both kernel sets so that they agree bit for bit on the activation.
+// ------------------------------------------------------------------------------------------------
+GPE_DEV float gpe_tanh(float x) {
+    float ax = fabsf(x);
+    float x2 = x * x;
+    // x - x^3/3 + 2x^5/15 - 17x^7/315 + 62x^9/2835
+    float p = fmaf(x2, 0.021869488536155203f, -0.053968253968253971f);
+    p = fmaf(x2, p, 0.13333333333333333f);
+    p = fmaf(x2, p, -0.33333333333333331f);
+    p = fmaf(x2 * x, p, x);
+    float e = __expf(2.0f * ax);                 // v_exp_f32; +inf for large ax -> r = 1
+    float r = 1.0f - __fdividef(2.0f, e + 1.0f);
+    r = copysignf(r, x);
+    return ax < 0.25f ? p : r;
+}
+
+// activation jets:  a = t + shift, a_k = s z_k, a_kk = s z_kk - 2 t s z_k^2   (t = tanh z, s = 1 - t^2)
+template <int D>
+GPE_DEV void act_from_stored(float t, const float* zk, const float* zkk, float shift, float* a /*[1+2D]*/) {
+    float s = fmaf(-t, t, 1.0f);
+    a[0] = t + shift;
+    float ts2 = 2.0f * t * s;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        a[1 + j] = s * zk[j];
+        a[1 + D + j] = fmaf(s, zkk[j], -ts2 * zk[j] * zk[j]);
+    }
+}
+
+// adjoint of the activation jets: given abar (adjoint of a-jets) and stored (t, z_k, z_kk) -> zbar
+//   zbar_kk = s abar_kk
+//   zbar_k  = s abar_k - 4 t s z_k abar_kk
+//   zbar    = s abar + sum_k [ (-2ts) z_k abar_k + ((-2ts) z_kk + (-2s^2+4t^2 s) z_k^2) abar_kk ]
+template <int D>
+GPE_DEV void act_adjoint(float t, const float* zk, const float* zkk, const float* ab /*[1+2D]*/, float* zb /*[1+2D]*/) {
+    float s = fmaf(-t, t, 1.0f);
+    float m2ts = -2.0f * t * s;
+    float q = s * (4.0f * t * t - 2.0f * s);
+    float acc = s * ab[0];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        float akb = ab[1 + j], akkb = ab[1 + D + j];
+        zb[1 + D + j] = s * akkb;
+        zb[1 + j] = fmaf(s, akb, 2.0f * m2ts * zk[j] * akkb);
+        acc = fmaf(m2ts * zk[j], akb, acc);
+        acc = fmaf(fmaf(m2ts, zkk[j], q * zk[j] * zk[j]), akkb, acc);
+    }
+    zb[0] = acc;
+}
+
+GPE_DEV float ipowf(float u, int p) {
+    float r = 1.0f;
+    for (int i = 0; i < p; ++i) r *= u;
+    return r;
+}
+
+// phi_n(x), phi_n', phi_n'' of the 1D harmonic oscillator (refine/harmonic_pinn_simulation.py:95-119).
+GPE_DEV void hermite_base(float x, int n, int deriv_mode, float norm, float& phi, float& phi1, float& phi2) {
+    float Hm2 = 0.f, Hm1 = 0.f, H = 1.f;
+    for (int k = 0; k < n; ++k) {
+        float Hn = 2.f * x * H - 2.f * (float)k * Hm1;
+        Hm2 = Hm1; Hm1 = H; H = Hn;
+    }
+    float w = expf(-0.5f * x * x);
+    float H1 = 0.f, H2 = 0.f;
+    if (deriv_mode == 0) {
+        H1 = 2.f * (float)n * Hm1;
+        H2 = 4.f * (float)n * (float)(n - 1) * Hm2;
+    }
+    phi = norm * (H * w);
+    phi1 = norm * w * (H1 - x * H);
+    phi2 = norm * w * (H2 - 2.f * x * H1 + (x * x - 1.f) * H);
+}
+
+GPE_DEV float potential_at(const Phys& ph, const float* xv, const float* Vpre, int64_t m) {
+    switch (ph.potential) {
+        case GPE_POT_PRECOMPUTED: return Vpre[m];
+        case GPE_POT_HARMONIC: {
+            float V = 0.f;
+            for (int k = 0; k < ph.dim; ++k) { float t = ph.omega[k] * xv[k]; V = fmaf(t, t, V); }
+            return ph.pot_scale * V;
+        }
+        case GPE_POT_GAUSSIAN: { float t = xv[0] - ph.pot_a; return expf(-t * t); }
+        case GPE_POT_PERIODIC: { float c = cosf(ph.pot_k * xv[0]); return ph.pot_v0 * c * c; }
+        default: return 0.f;
+    }
+}
+
+// block-wide sum of a double over 256 threads -> valid in thread 0
+GPE_DEV double block_sum_256(double v, double* red /* >= 4 doubles of LDS */) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) {
+        int nw = (blockDim.x + 63) >> 6;
+        for (int i = 0; i < nw; ++i) r += red[i];
+    }
+    return r;
+}

@@ -1,0 +1,844 @@
+// gpe_engine.hip -- step orchestrator + C ABI (include/gpe_hip.h) of libgpe_hip.so.  gfx950 only.
+//
+// One engine = one GPU = one stream.  A training step (the epoch body of
+// refine/harmonic_pinn_simulation.py:328-361 / nb c10:L84-103) is three phases:
+//   begin    : [pack weights] zero accumulators; jet forward on the collocation batch; head (u, Hu, sums)
+//              [+ symmetry batch forward]                        -> "sums" exchange buffer (double[8])
+//   backward : lambda, residual, seeds; reverse pass; boundary batch fwd+bwd [+ symmetry bwd]
+//                                                                 -> "grad" exchange buffer (float[P+4])
+//   update   : grad-norm clip, Adam, LR scheduler, history record (one single-workgroup kernel)
+// With world_size > 1 the caller all-reduces the two exchange buffers between the phases (RCCL).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "gpe_common.h"
+#include "gpe_head.h"
+#include "gpe_generic.h"
+#include "gpe_fused.h"
+
+static thread_local std::string g_create_error;
+
+#define HIPCHK(e, call)                                                                          \
+    do {                                                                                         \
+        hipError_t _st = (call);                                                                 \
+        if (_st != hipSuccess) {                                                                 \
+            char _b[512];                                                                        \
+            snprintf(_b, sizeof _b, "%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(_st)); \
+            (e)->err = _b;                                                                       \
+            return GPE_ERR_HIP;                                                                  \
+        }                                                                                        \
+    } while (0)
+
+#define FAIL(e, code, ...)                                \
+    do {                                                  \
+        char _b[512];                                     \
+        snprintf(_b, sizeof _b, __VA_ARGS__);             \
+        (e)->err = _b;                                    \
+        return (code);                                    \
+    } while (0)
+
+static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
+
+// ------------------------------------------------------------------------------------------------
+// update kernel: clip_grad_norm_ + Adam + scheduler + record   (refine/...:359-361, 364-381)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_update(int P, float* __restrict__ theta, float* __restrict__ am,
+                                                  float* __restrict__ av, const float* __restrict__ grad,
+                                                  const double* __restrict__ sums, const double* __restrict__ lsums,
+                                                  Phys ph, OptCfg oc, OptDev* __restrict__ od,
+                                                  gpe_scalars* __restrict__ hist, int cap, gpe_scalars* __restrict__ last,
+                                                  double bc_cnt, int do_update) {
+    __shared__ double red[16];
+    __shared__ float s_coef, s_ss, s_b2s;
+    __shared__ int s_skip;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < P; i += 1024) { double g = grad[i]; acc += g * g; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int i = 0; i < 16; ++i) tot += red[i];
+        double gn = sqrt(tot);
+        double num = sums[S_NUM], den = sums[S_DEN];
+        double lam = (double)(float)(num / den);
+        double I = (double)((float)den * ph.dx);
+        double sr2 = (double)grad[P + GT_SUM_R2];
+        double pde = sr2 / ph.n_global;
+        double nrm = (I - 1.0) * (I - 1.0);
+        double bc = bc_cnt > 0 ? lsums[LS_BC_SE2] / bc_cnt : 0.0;
+        double sym = ph.w_sym != 0.f ? sums[S_SYM] / ph.n_global : 0.0;
+        double orth = 0.0;
+        for (int j = 0; j < ph.n_orth; ++j) { double oj = sums[S_ORTH0 + j] * ph.dx; orth += oj * oj; }
+        double loss = ph.w_pde * pde + ph.w_bc * bc + ph.w_norm * nrm + ph.w_sym * sym + ph.w_orth * orth;
+        int skip = !(isfinite(loss) && isfinite(gn));
+        long long step = od->step + (do_update && !skip ? 1 : 0);
+        double lr = od->lr;
+        float coef = 1.0f;
+        if (oc.clip_norm > 0.f) coef = (float)fmin(1.0, (double)oc.clip_norm / (gn + 1e-6));
+        double bc1 = 1.0 - pow((double)oc.beta1, (double)step);
+        double bc2 = 1.0 - pow((double)oc.beta2, (double)step);
+        s_coef = coef;
+        s_ss = (float)(lr / bc1);
+        s_b2s = (float)sqrt(bc2);
+        s_skip = skip || !do_update;
+        gpe_scalars r;
+        r.loss = loss; r.pde = pde; r.bc = bc; r.norm = nrm; r.sym = sym; r.orth = orth; r.mu = lam;
+        r.num = num; r.den = den; r.sum_r2 = sr2; r.integral = I; r.grad_norm = gn; r.lr = lr;
+        r.step = (double)step; r.reserved[0] = skip ? 1.0 : 0.0; r.reserved[1] = 0.0;
+        *last = r;
+        if (do_update) {
+            if (!skip) {
+                hist[(step - 1) % cap] = r;
+                od->step = step;
+                // scheduler.step(total_loss)
+                if (oc.sched == GPE_SCHED_COSINE_LOSS) {           // quirk Q4: the loss value is the epoch
+                    double epoch = (double)(float)loss, T_cur, T_i;
+                    if (epoch >= oc.T_0) {
+                        if (oc.T_mult == 1.0f) { T_cur = fmod(epoch, (double)oc.T_0); T_i = oc.T_0; }
+                        else {
+                            int n = (int)(log(epoch / oc.T_0 * (oc.T_mult - 1.0) + 1.0) / log((double)oc.T_mult));
+                            T_cur = epoch - oc.T_0 * (pow((double)oc.T_mult, n) - 1.0) / (oc.T_mult - 1.0);
+                            T_i = oc.T_0 * pow((double)oc.T_mult, n);
+                        }
+                    } else { T_i = oc.T_0; T_cur = epoch; }
+                    od->lr = oc.eta_min + (od->lr0 - oc.eta_min) * (1.0 + cos(M_PI * T_cur / T_i)) / 2.0;
+                } else if (oc.sched == GPE_SCHED_PLATEAU) {        // ReduceLROnPlateau(mode='min', rel threshold)
+                    if (loss < od->best * (1.0 - oc.threshold)) { od->best = loss; od->num_bad = 0; }
+                    else od->num_bad += 1;
+                    if (od->num_bad > oc.patience) {
+                        double nl = fmax(od->lr * oc.factor, (double)oc.min_lr);
+                        if (od->lr - nl > 1e-8) od->lr = nl;
+                        od->num_bad = 0;
+                    }
+                }
+            } else {
+                od->nonfinite = 1;
+            }
+        }
+    }
+    __syncthreads();
+    if (s_skip) return;
+    const float coef = s_coef, ss = s_ss, b2s = s_b2s;
+    const float b1 = oc.beta1, b2 = oc.beta2, eps = oc.eps;
+    for (int i = threadIdx.x; i < P; i += 1024) {
+        float g = grad[i] * coef;
+        float m = am[i], v = av[i];
+        m = m + (g - m) * (1.0f - b1);                 // exp_avg.lerp_(grad, 1-beta1)
+        v = v * b2 + (1.0f - b2) * g * g;              // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1-beta2)
+        float denom = sqrtf(v) / b2s + eps;
+        theta[i] = theta[i] - ss * (m / denom);        // param.addcdiv_(exp_avg, denom, value=-step_size)
+        am[i] = m; av[i] = v;
+    }
+}
+
+__global__ void k_tail(float* grad_tail, const double* dsc) { grad_tail[GT_SUM_R2] = (float)dsc[0]; }
+
+// ------------------------------------------------------------------------------------------------
+struct Batch {
+    const float* x = nullptr;      // [n][dim]
+    const float* V = nullptr;
+    int64_t n = 0, ld = 0;
+    int C = 1;
+    float* O = nullptr;            // [C][n_out][ld]
+    float* Ob = nullptr;
+    float* u = nullptr;            // [n_out][ld]  (main batch)
+    float* Hu = nullptr;
+    float* stored = nullptr;       // fused: fragment-native stored activations
+    std::vector<float*> S;         // generic: per hidden layer [C][H][ld]
+    float* A0 = nullptr;           // generic adjoint ping/pong [C][maxW][ld]
+    float* A1 = nullptr;
+    float* xown = nullptr;         // owned copy of points (symmetry batch)
+    std::vector<void*> allocs;
+};
+
+struct gpe_engine {
+    gpe_config cfg;
+    NetDesc nd;
+    Phys ph;
+    OptCfg oc;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int path = GPE_PATH_GENERIC;
+    int H = 0;                     // uniform hidden width (fused)
+    int P = 0, Ppad = 0;
+    float base_norm = 1.f;
+    float *theta = nullptr, *am = nullptr, *av = nullptr, *grad = nullptr;   // grad: P + GT_COUNT
+    double* dbl = nullptr;         // [S_COUNT sums | LS_COUNT local | 4 misc]
+    OptDev* od = nullptr;
+    gpe_scalars *hist = nullptr, *last = nullptr;
+    int cap = 65536;
+    float *Wpk = nullptr, *WpkT = nullptr, *gslab = nullptr;
+    int nslab = 0;
+    bool packed_dirty = true;
+    bool ext_exchange = false;
+    const float** orth_dev = nullptr;
+    const float* orth_host[GPE_MAX_ORTH] = {nullptr, nullptr, nullptr, nullptr};
+    Batch main, bc, sym, aux;
+    const float* bc_target = nullptr;
+    int num_cu = 256;
+    int phase = 0;                 // 0 idle, 1 after begin, 2 after backward
+    std::string err;
+    double* sums() { return dbl; }
+    double* lsums() { return dbl + S_COUNT; }
+    double* dsc() { return dbl + S_COUNT + LS_COUNT; }
+};
+
+static void free_batch(Batch& b) {
+    for (void* p : b.allocs) (void)hipFree(p);
+    b = Batch();
+}
+
+template <typename T>
+static int dev_alloc(gpe_engine* e, Batch* b, T** out, size_t count) {
+    void* p = nullptr;
+    HIPCHK(e, hipMalloc(&p, count * sizeof(T) + 256));
+    HIPCHK(e, hipMemsetAsync(p, 0, count * sizeof(T) + 256, e->stream));
+    if (b) b->allocs.push_back(p);
+    *out = (T*)p;
+    return GPE_OK;
+}
+
+static int setup_batch(gpe_engine* e, Batch& b, const float* x, int64_t n, int C, bool with_head, const float* V) {
+    if (b.n == n && b.C == C && b.O) { b.x = x; b.V = V; return GPE_OK; }
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    float* keep_xown = nullptr;
+    (void)keep_xown;
+    free_batch(b);
+    b.x = x; b.V = V; b.n = n; b.C = C;
+    b.ld = round_up(n, 64);
+    const int no = e->nd.n_out;
+    int rc;
+    if ((rc = dev_alloc(e, &b, &b.O, (size_t)C * no * b.ld))) return rc;
+    if ((rc = dev_alloc(e, &b, &b.Ob, (size_t)C * no * b.ld))) return rc;
+    if (with_head) {
+        if ((rc = dev_alloc(e, &b, &b.u, (size_t)no * b.ld))) return rc;
+        if ((rc = dev_alloc(e, &b, &b.Hu, (size_t)no * b.ld))) return rc;
+    }
+    const int L = e->nd.n_lin - 1;
+    if (e->path == GPE_PATH_FUSED) {
+        int64_t ntiles = (n + 15) / 16;
+        size_t cnt = (size_t)ntiles * (L - 1) * C * e->H * 16;
+        if ((rc = dev_alloc(e, &b, &b.stored, cnt ? cnt : 4))) return rc;
+    } else {
+        int maxW = 1;
+        for (int h = 0; h < L; ++h) {
+            float* s;
+            if ((rc = dev_alloc(e, &b, &s, (size_t)C * e->nd.width[h + 1] * b.ld))) return rc;
+            b.S.push_back(s);
+            if (e->nd.width[h + 1] > maxW) maxW = e->nd.width[h + 1];
+        }
+        if ((rc = dev_alloc(e, &b, &b.A0, (size_t)C * maxW * b.ld))) return rc;
+        if ((rc = dev_alloc(e, &b, &b.A1, (size_t)C * maxW * b.ld))) return rc;
+    }
+    return GPE_OK;
+}
+
+// ---- MLP forward / backward dispatch ---------------------------------------------------------------
+#define DISPATCH_C(Cv, ...)                                           \
+    switch (Cv) {                                                     \
+        case 1: { constexpr int CC = 1; __VA_ARGS__; } break;         \
+        case 3: { constexpr int CC = 3; __VA_ARGS__; } break;         \
+        case 5: { constexpr int CC = 5; __VA_ARGS__; } break;         \
+        case 7: { constexpr int CC = 7; __VA_ARGS__; } break;         \
+        default: FAIL(e, GPE_ERR_INVALID, "bad channel count %d", Cv); \
+    }
+
+template <int HH, int CC>
+static void launch_f_forward(gpe_engine* e, Batch& b, unsigned grid, int store) {
+    if (e->nd.n_out == 1)
+        hipLaunchKernelGGL((f_forward<HH, CC, 1>), dim3(grid), dim3(256), 0, e->stream, e->nd, e->theta, e->Wpk, b.x,
+                           b.stored, b.O, b.n, b.ld, store);
+    else
+        hipLaunchKernelGGL((f_forward<HH, CC, 2>), dim3(grid), dim3(256), 0, e->stream, e->nd, e->theta, e->Wpk, b.x,
+                           b.stored, b.O, b.n, b.ld, store);
+}
+template <int HH, int CC>
+static void launch_f_backward(gpe_engine* e, Batch& b, unsigned grid, size_t lds) {
+    if (e->nd.n_out == 1)
+        hipLaunchKernelGGL((f_backward<HH, CC, 1>), dim3(grid), dim3(256), lds, e->stream, e->nd, e->theta, e->WpkT,
+                           b.x, b.stored, b.Ob, e->gslab, b.n, b.ld, e->Ppad);
+    else
+        hipLaunchKernelGGL((f_backward<HH, CC, 2>), dim3(grid), dim3(256), lds, e->stream, e->nd, e->theta, e->WpkT,
+                           b.x, b.stored, b.Ob, e->gslab, b.n, b.ld, e->Ppad);
+}
+
+static unsigned fused_grid(gpe_engine* e, int64_t n) {
+    int64_t ntiles = (n + 15) / 16;
+    int64_t blocks = (ntiles + 3) / 4;
+    int64_t cap = (int64_t)e->num_cu * 2;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+static size_t fused_bwd_lds(gpe_engine* e) { return ((size_t)e->Ppad + 4 * 2 * 16 * F_PITCH) * sizeof(float); }
+
+static int ensure_packed(gpe_engine* e) {
+    if (e->path != GPE_PATH_FUSED || !e->packed_dirty) return GPE_OK;
+    const int L = e->nd.n_lin - 1;
+    int total = (L - 1) * e->H * e->H;
+    hipLaunchKernelGGL(k_pack_weights, dim3(cdiv(total, 256)), dim3(256), 0, e->stream, e->nd, e->H, e->theta, e->Wpk,
+                       e->WpkT);
+    HIPCHK(e, hipGetLastError());
+    e->packed_dirty = false;
+    return GPE_OK;
+}
+
+static int mlp_forward(gpe_engine* e, Batch& b, bool store) {
+    if (b.n <= 0) return GPE_OK;
+    if (e->path == GPE_PATH_FUSED) {
+        int rc = ensure_packed(e);
+        if (rc) return rc;
+        unsigned grid = fused_grid(e, b.n);
+        if (e->H == 64) { DISPATCH_C(b.C, launch_f_forward<64, CC>(e, b, grid, store ? 1 : 0)); }
+        else            { DISPATCH_C(b.C, launch_f_forward<32, CC>(e, b, grid, store ? 1 : 0)); }
+    } else {
+        const NetDesc& nd = e->nd;
+        for (int lin = 0; lin < nd.n_lin; ++lin) {
+            const float* Sprev = lin > 0 ? b.S[lin - 1] : nullptr;
+            float* Out = (lin == nd.n_lin - 1) ? b.O : b.S[lin];
+            dim3 grid(cdiv(b.n, 256), cdiv(nd.width[lin + 1], G_FB));
+            DISPATCH_C(b.C, hipLaunchKernelGGL((g_fwd_layer<CC>), grid, dim3(256), 0, e->stream, nd, lin, e->theta, b.x,
+                                                Sprev, Out, b.n, b.ld));
+        }
+    }
+    HIPCHK(e, hipGetLastError());
+    return GPE_OK;
+}
+
+// accumulates into e->grad
+static int mlp_backward(gpe_engine* e, Batch& b) {
+    if (b.n <= 0) return GPE_OK;
+    if (e->path == GPE_PATH_FUSED) {
+        unsigned grid = fused_grid(e, b.n);
+        size_t lds = fused_bwd_lds(e);
+        if (e->H == 64) { DISPATCH_C(b.C, launch_f_backward<64, CC>(e, b, grid, lds)); }
+        else            { DISPATCH_C(b.C, launch_f_backward<32, CC>(e, b, grid, lds)); }
+        HIPCHK(e, hipGetLastError());
+        hipLaunchKernelGGL(k_grad_reduce, dim3(cdiv(e->P, 256)), dim3(256), 0, e->stream, e->gslab, (int)grid, e->Ppad,
+                           e->P, e->grad);
+    } else {
+        const NetDesc& nd = e->nd;
+        float* Zb = b.Ob;
+        float* nxt = b.A0;
+        for (int lin = nd.n_lin - 1; lin >= 0; --lin) {
+            const int K = nd.width[lin], Ho = nd.width[lin + 1];
+            const float* Sprev = lin > 0 ? b.S[lin - 1] : nullptr;
+            dim3 gw(Ho, cdiv(K, G_KB));
+            DISPATCH_C(b.C, hipLaunchKernelGGL((g_bwd_weight<CC>), gw, dim3(256), 0, e->stream, nd, lin, b.x, Sprev, Zb,
+                                                e->grad, b.n, b.ld));
+            if (lin > 0) {
+                dim3 gd(cdiv(b.n, 256), cdiv(K, G_FB));
+                DISPATCH_C(b.C, hipLaunchKernelGGL((g_bwd_data<CC>), gd, dim3(256), 0, e->stream, nd, lin, e->theta, Zb,
+                                                    nxt, b.n, b.ld));
+                dim3 ga(cdiv(b.n, 256), K);
+                DISPATCH_C(b.C, hipLaunchKernelGGL((g_bwd_act<CC>), ga, dim3(256), 0, e->stream, K, Sprev, nxt, b.n, b.ld));
+                Zb = nxt;
+                nxt = (nxt == b.A0) ? b.A1 : b.A0;
+            }
+        }
+    }
+    HIPCHK(e, hipGetLastError());
+    return GPE_OK;
+}
+
+// ---- config -> device structs ------------------------------------------------------------------------
+static void fill_phys(gpe_engine* e) {
+    const gpe_config& c = e->cfg;
+    Phys& p = e->ph;
+    memset(&p, 0, sizeof p);
+    p.dim = c.layers[0]; p.n_out = c.layers[c.n_layers - 1]; p.complex_psi = c.complex_psi;
+    p.kin = c.kinetic_coeff; p.potential = c.potential; p.pot_scale = c.pot_scale;
+    for (int k = 0; k < 3; ++k) p.omega[k] = c.omega[k];
+    p.pot_a = c.pot_a; p.pot_v0 = c.pot_v0; p.pot_k = c.pot_k; p.omega_rot = c.omega_rot;
+    p.gamma = c.gamma; p.p = c.p; p.abs_power = c.abs_power; p.base_mode = c.base_mode; p.base_deriv = c.base_deriv;
+    p.perturb_scale = c.perturb_scale; p.bc_nn_scale = c.bc_nn_scale;
+    p.w_pde = c.w_pde; p.w_bc = c.w_bc; p.w_norm = c.w_norm; p.w_sym = c.w_sym; p.w_orth = c.w_orth;
+    p.sym_sign = c.sym_sign; p.dx = c.dx;
+    p.n_global = (double)(c.n_global > 0 ? c.n_global : (e->main.n > 0 ? e->main.n : 1));
+    p.inv_world = 1.0f / (float)(c.world_size > 0 ? c.world_size : 1);
+    int no = 0;
+    for (int j = 0; j < GPE_MAX_ORTH; ++j) if (e->orth_host[j]) no = j + 1;
+    p.n_orth = no;
+    if (c.base_mode >= 0) {
+        double f = 1.0;
+        for (int i = 2; i <= c.base_mode; ++i) f *= i;
+        e->base_norm = (float)pow(pow(2.0, c.base_mode) * f * sqrt(M_PI), -0.5);
+    }
+    OptCfg& o = e->oc;
+    o.beta1 = c.beta1; o.beta2 = c.beta2; o.eps = c.eps; o.clip_norm = c.clip_norm; o.sched = c.sched;
+    o.T_0 = c.T_0; o.T_mult = c.T_mult; o.eta_min = c.eta_min; o.factor = c.factor; o.patience = c.patience;
+    o.min_lr = c.min_lr; o.threshold = c.threshold;
+}
+
+static int reset_opt(gpe_engine* e, float lr) {
+    OptDev h;
+    memset(&h, 0, sizeof h);
+    h.lr = lr; h.lr0 = lr; h.best = INFINITY; h.num_bad = 0; h.nonfinite = 0; h.step = 0;
+    HIPCHK(e, hipMemcpyAsync(e->od, &h, sizeof h, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemsetAsync(e->am, 0, (size_t)e->P * sizeof(float), e->stream));
+    HIPCHK(e, hipMemsetAsync(e->av, 0, (size_t)e->P * sizeof(float), e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return GPE_OK;
+}
+
+extern "C" {
+
+int gpe_abi_version(void) { return GPE_ABI_VERSION; }
+size_t gpe_sizeof_config(void) { return sizeof(gpe_config); }
+size_t gpe_sizeof_scalars(void) { return sizeof(gpe_scalars); }
+int64_t gpe_exchange_dbl_count(void) { return S_COUNT + LS_COUNT + 4; }
+
+int gpe_use_external_exchange(gpe_engine* e, void* d_dbl, int64_t n_dbl, void* d_grad, int64_t n_grad) {
+    if (!e || !d_dbl || !d_grad) return GPE_ERR_INVALID;
+    if (n_dbl < S_COUNT + LS_COUNT + 4 || n_grad < e->P + GT_COUNT) FAIL(e, GPE_ERR_INVALID, "external exchange buffers too small");
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (!e->ext_exchange) { (void)hipFree(e->dbl); (void)hipFree(e->grad); }
+    e->dbl = (double*)d_dbl; e->grad = (float*)d_grad; e->ext_exchange = true;
+    return GPE_OK;
+}
+
+const char* gpe_last_error(const gpe_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+int gpe_active_path(const gpe_engine* e) { return e ? e->path : GPE_ERR_INVALID; }
+
+int64_t gpe_param_count(const gpe_engine* e) { return e ? e->P : -1; }
+
+int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine** out) {
+    if (!cfg || !out) { g_create_error = "null argument"; return GPE_ERR_INVALID; }
+    *out = nullptr;
+    gpe_engine* e = new gpe_engine();
+    auto bail = [&](int code) { g_create_error = e->err; delete e; return code; };
+#define CFAIL(...) do { char _b[512]; snprintf(_b, sizeof _b, __VA_ARGS__); e->err = _b; return bail(GPE_ERR_INVALID); } while (0)
+    if (cfg->abi_version != GPE_ABI_VERSION) CFAIL("abi_version %d != %d", cfg->abi_version, GPE_ABI_VERSION);
+    e->cfg = *cfg;
+    const gpe_config& c = e->cfg;
+    if (c.n_layers < 3 || c.n_layers > GPE_MAX_LAYERS) CFAIL("n_layers must be in [3,%d]", GPE_MAX_LAYERS);
+    const int dim = c.layers[0], no = c.layers[c.n_layers - 1];
+    if (dim < 1 || dim > GPE_MAX_DIM) CFAIL("dim must be 1..3");
+    if (no < 1 || no > 2) CFAIL("output width must be 1 or 2");
+    if (c.complex_psi && (no != 2 || c.p != 3)) CFAIL("complex psi needs out=2 and p=3");
+    if (!c.complex_psi && no != 1) CFAIL("real psi needs out=1");
+    if (c.potential < 0 || c.potential > GPE_POT_NONE) CFAIL("Unknown potential type: %d", c.potential);
+    if (c.base_mode >= 0 && (dim != 1 || no != 1)) CFAIL("Hermite base needs dim=1, out=1");
+    if (c.p < 1 || c.p > 32) CFAIL("power p must be in [1,32]");
+    if (c.omega_rot != 0.f && (!c.complex_psi || dim < 2)) CFAIL("rotation needs complex psi and dim>=2");
+    for (int i = 1; i < c.n_layers - 1; ++i)
+        if (c.layers[i] < 1 || c.layers[i] > 1024) CFAIL("hidden width %d out of range", c.layers[i]);
+    NetDesc& nd = e->nd;
+    memset(&nd, 0, sizeof nd);
+    nd.n_lin = c.n_layers - 1; nd.dim = dim; nd.n_out = no; nd.shift = c.activation == GPE_ACT_TANH_PLUS1 ? 1.f : 0.f;
+    int off = 0;
+    for (int i = 0; i < c.n_layers; ++i) nd.width[i] = c.layers[i];
+    for (int j = 0; j < nd.n_lin; ++j) {
+        nd.offW[j] = off; off += nd.width[j] * nd.width[j + 1];
+        nd.offB[j] = off; off += nd.width[j + 1];
+    }
+    nd.n_params = off;
+    e->P = off;
+    e->Ppad = (int)round_up(off, 64);
+    // path selection: fused kernels need >= 2 hidden layers of one width H in {32, 64}
+    bool uniform = true;
+    for (int i = 2; i < c.n_layers - 1; ++i) uniform = uniform && (c.layers[i] == c.layers[1]);
+    const int H = c.layers[1];
+    const int Lh = c.n_layers - 2;
+    size_t lds_need = ((size_t)e->Ppad + 4 * 2 * 16 * F_PITCH) * sizeof(float);
+    bool fused_ok = uniform && (H == 32 || H == 64) && Lh >= 2 && lds_need <= 160 * 1024;
+    if (c.path == GPE_PATH_FUSED && !fused_ok) CFAIL("fused path needs >=2 hidden layers of width 32 or 64 (and P*4 <= 160KB LDS)");
+    e->path = (c.path == GPE_PATH_GENERIC || !fused_ok) ? GPE_PATH_GENERIC : GPE_PATH_FUSED;
+    e->H = H;
+#undef CFAIL
+    e->device = device;
+    e->stream = (hipStream_t)hip_stream;
+    hipError_t st = hipSetDevice(device);
+    if (st != hipSuccess) { e->err = std::string("hipSetDevice: ") + hipGetErrorString(st); return bail(GPE_ERR_HIP); }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) e->num_cu = prop.multiProcessorCount;
+    e->cap = c.history_capacity > 0 ? c.history_capacity : 65536;
+    auto alloc = [&](void** p, size_t bytes) -> bool {
+        hipError_t s2 = hipMalloc(p, bytes + 256);
+        if (s2 != hipSuccess) { e->err = std::string("hipMalloc: ") + hipGetErrorString(s2); return false; }
+        (void)hipMemset(*p, 0, bytes + 256);
+        return true;
+    };
+    bool ok = alloc((void**)&e->theta, (size_t)e->P * 4) && alloc((void**)&e->am, (size_t)e->P * 4) &&
+              alloc((void**)&e->av, (size_t)e->P * 4) && alloc((void**)&e->grad, ((size_t)e->P + GT_COUNT) * 4) &&
+              alloc((void**)&e->dbl, (S_COUNT + LS_COUNT + 4) * sizeof(double)) && alloc((void**)&e->od, sizeof(OptDev)) &&
+              alloc((void**)&e->hist, (size_t)e->cap * sizeof(gpe_scalars)) && alloc((void**)&e->last, sizeof(gpe_scalars)) &&
+              alloc((void**)&e->orth_dev, GPE_MAX_ORTH * sizeof(float*));
+    if (ok && e->path == GPE_PATH_FUSED) {
+        e->nslab = e->num_cu * 2;
+        ok = alloc((void**)&e->Wpk, (size_t)(Lh - 1) * H * H * 4) && alloc((void**)&e->WpkT, (size_t)(Lh - 1) * H * H * 4) &&
+             alloc((void**)&e->gslab, (size_t)e->nslab * e->Ppad * 4);
+        if (ok) {
+            // allow > 64 KB dynamic LDS for the reverse kernels
+            int lds = (int)lds_need;
+#define SETLDS(HH, CC, NO) (void)hipFuncSetAttribute((const void*)f_backward<HH, CC, NO>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)
+            SETLDS(64, 1, 1); SETLDS(64, 3, 1); SETLDS(64, 5, 1); SETLDS(64, 7, 1);
+            SETLDS(64, 1, 2); SETLDS(64, 3, 2); SETLDS(64, 5, 2); SETLDS(64, 7, 2);
+            SETLDS(32, 1, 1); SETLDS(32, 3, 1); SETLDS(32, 5, 1); SETLDS(32, 7, 1);
+            SETLDS(32, 1, 2); SETLDS(32, 3, 2); SETLDS(32, 5, 2); SETLDS(32, 7, 2);
+#undef SETLDS
+        }
+    }
+    if (!ok) return bail(GPE_ERR_NOMEM);
+    fill_phys(e);
+    int rc = reset_opt(e, c.lr);
+    if (rc) return bail(rc);
+    *out = e;
+    return GPE_OK;
+}
+
+void gpe_destroy(gpe_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    free_batch(e->main); free_batch(e->bc); free_batch(e->sym); free_batch(e->aux);
+    if (e->ext_exchange) { e->grad = nullptr; e->dbl = nullptr; }
+    void* ps[] = {e->theta, e->am, e->av, e->grad, e->dbl, e->od, e->hist, e->last, (void*)e->orth_dev, e->Wpk, e->WpkT, e->gslab};
+    for (void* p : ps) if (p) (void)hipFree(p);
+    delete e;
+}
+
+int gpe_synchronize(gpe_engine* e) {
+    if (!e) return GPE_ERR_INVALID;
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return GPE_OK;
+}
+
+int gpe_set_params(gpe_engine* e, const float* h, size_t n) {
+    if (!e || !h) return GPE_ERR_INVALID;
+    if ((int64_t)n != e->P) FAIL(e, GPE_ERR_INVALID, "set_params: got %zu floats, model has %d", n, e->P);
+    HIPCHK(e, hipMemcpyAsync(e->theta, h, n * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    e->packed_dirty = true;
+    return GPE_OK;
+}
+int gpe_get_params(gpe_engine* e, float* h, size_t n) {
+    if (!e || !h) return GPE_ERR_INVALID;
+    if ((int64_t)n != e->P) FAIL(e, GPE_ERR_INVALID, "get_params: got %zu floats, model has %d", n, e->P);
+    HIPCHK(e, hipMemcpyAsync(h, e->theta, n * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return GPE_OK;
+}
+int gpe_get_grad(gpe_engine* e, float* h, size_t n) {
+    if (!e || !h) return GPE_ERR_INVALID;
+    if ((int64_t)n != e->P) FAIL(e, GPE_ERR_INVALID, "get_grad: size mismatch");
+    HIPCHK(e, hipMemcpyAsync(h, e->grad, n * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return GPE_OK;
+}
+int gpe_get_adam_state(gpe_engine* e, float* hm, float* hv, size_t n, int64_t* step) {
+    if (!e) return GPE_ERR_INVALID;
+    if ((int64_t)n != e->P) FAIL(e, GPE_ERR_INVALID, "get_adam_state: size mismatch");
+    OptDev h;
+    if (hm) HIPCHK(e, hipMemcpyAsync(hm, e->am, n * 4, hipMemcpyDeviceToHost, e->stream));
+    if (hv) HIPCHK(e, hipMemcpyAsync(hv, e->av, n * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipMemcpyAsync(&h, e->od, sizeof h, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (step) *step = h.step;
+    return GPE_OK;
+}
+int gpe_set_adam_state(gpe_engine* e, const float* hm, const float* hv, size_t n, int64_t step) {
+    if (!e || !hm || !hv) return GPE_ERR_INVALID;
+    if ((int64_t)n != e->P) FAIL(e, GPE_ERR_INVALID, "set_adam_state: size mismatch");
+    OptDev h;
+    HIPCHK(e, hipMemcpyAsync(&h, e->od, sizeof h, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    h.step = step;
+    HIPCHK(e, hipMemcpyAsync(e->am, hm, n * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(e->av, hv, n * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(e->od, &h, sizeof h, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return GPE_OK;
+}
+int gpe_reset_optimizer(gpe_engine* e, float lr) {
+    if (!e) return GPE_ERR_INVALID;
+    e->cfg.lr = lr;
+    return reset_opt(e, lr);
+}
+
+int gpe_bind_points(gpe_engine* e, const float* d_x, int64_t n_local, const float* d_V) {
+    if (!e) return GPE_ERR_INVALID;
+    if (!d_x || n_local <= 0) FAIL(e, GPE_ERR_INVALID, "bind_points: need n_local > 0 points");
+    if (e->cfg.potential == GPE_POT_PRECOMPUTED && !d_V) FAIL(e, GPE_ERR_INVALID, "precomputed potential requested but d_V is NULL");
+    int rc = setup_batch(e, e->main, d_x, n_local, 1 + 2 * e->nd.dim, true, d_V);
+    if (rc) return rc;
+    if (e->cfg.w_sym != 0.f) {
+        // symmetry batch: [x ; -x], value only
+        if (e->sym.n != 2 * n_local) {
+            free_batch(e->sym);
+            float* xs = nullptr;
+            Batch tmp;
+            if ((rc = dev_alloc(e, &tmp, &xs, (size_t)2 * n_local * e->nd.dim))) return rc;
+            if ((rc = setup_batch(e, e->sym, xs, 2 * n_local, 1, false, nullptr))) return rc;
+            e->sym.allocs.push_back(tmp.allocs[0]);
+            e->sym.xown = xs;
+        }
+        hipLaunchKernelGGL(k_make_sym_points, dim3(cdiv(n_local * e->nd.dim, 256)), dim3(256), 0, e->stream, d_x,
+                           e->sym.xown, n_local, e->nd.dim);
+        HIPCHK(e, hipGetLastError());
+    }
+    fill_phys(e);
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return GPE_OK;
+}
+
+int gpe_bind_boundary(gpe_engine* e, const float* d_xb, int64_t n_b, const float* d_target) {
+    if (!e) return GPE_ERR_INVALID;
+    if (!d_xb || n_b <= 0) { free_batch(e->bc); e->bc_target = nullptr; return GPE_OK; }
+    e->bc_target = d_target;
+    int rc = setup_batch(e, e->bc, d_xb, n_b, 1, false, nullptr);
+    if (rc) return rc;
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return GPE_OK;
+}
+
+int gpe_bind_orth(gpe_engine* e, int k, const float* d_psi) {
+    if (!e || k < 0 || k >= GPE_MAX_ORTH) return GPE_ERR_INVALID;
+    e->orth_host[k] = d_psi;
+    HIPCHK(e, hipMemcpyAsync((void*)e->orth_dev, e->orth_host, sizeof e->orth_host, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    fill_phys(e);
+    return GPE_OK;
+}
+
+// ---- forward-only ----------------------------------------------------------------------------------
+static int aux_forward(gpe_engine* e, const float* d_x, int64_t n, int C) {
+    int rc = setup_batch(e, e->aux, d_x, n, C, true, nullptr);
+    if (rc) return rc;
+    return mlp_forward(e, e->aux, false);
+}
+
+int gpe_forward(gpe_engine* e, const float* d_x, int64_t n, float* d_out) {
+    if (!e || !d_x || !d_out || n <= 0) return GPE_ERR_INVALID;
+    int rc = aux_forward(e, d_x, n, 1);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_copy_values, dim3(cdiv(n, 256)), dim3(256), 0, e->stream, e->aux.O, d_out, n, e->aux.ld, e->nd.n_out);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return GPE_OK;
+}
+
+int gpe_forward_jets(gpe_engine* e, const float* d_x, int64_t n, float* d_jets) {
+    if (!e || !d_x || !d_jets || n <= 0) return GPE_ERR_INVALID;
+    const int C = 1 + 2 * e->nd.dim;
+    int rc = aux_forward(e, d_x, n, C);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_copy_jets, dim3(cdiv(n, 256)), dim3(256), 0, e->stream, e->aux.O, d_jets, n, e->aux.ld, e->nd.n_out, C);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return GPE_OK;
+}
+
+int gpe_eval_density(gpe_engine* e, const float* d_x, int64_t n, float dx, int abs_flag, float* d_u, float* d_dens) {
+    if (!e || !d_x || n <= 0) return GPE_ERR_INVALID;
+    int rc = aux_forward(e, d_x, n, 1);
+    if (rc) return rc;
+    double* acc = e->dsc() + 1;
+    HIPCHK(e, hipMemsetAsync(acc, 0, sizeof(double), e->stream));
+    hipLaunchKernelGGL(k_eval_u, dim3(cdiv(n, 256)), dim3(256), 0, e->stream, e->ph, e->base_norm, d_x, e->aux.O, e->aux.u,
+                       acc, n, e->aux.ld);
+    hipLaunchKernelGGL(k_eval_finish, dim3(cdiv(n, 256)), dim3(256), 0, e->stream, e->aux.u, acc, dx, abs_flag, d_u, d_dens,
+                       n, e->aux.ld, e->nd.n_out);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return GPE_OK;
+}
+
+// ---- the step ------------------------------------------------------------------------------------------
+static int launch_head_pde(gpe_engine* e) {
+    Batch& b = e->main;
+    dim3 g(cdiv(b.n, 256));
+    DISPATCH_C(b.C, hipLaunchKernelGGL((k_head_pde<CC>), g, dim3(256), 0, e->stream, e->ph, e->base_norm, b.x, b.V, b.O,
+                                        (const float* const*)e->orth_dev, b.u, b.Hu, e->sums(), b.n, b.ld));
+    HIPCHK(e, hipGetLastError());
+    return GPE_OK;
+}
+static int launch_seed_pde(gpe_engine* e, float* d_resid, int want_seeds) {
+    Batch& b = e->main;
+    dim3 g(cdiv(b.n, 256));
+    DISPATCH_C(b.C, hipLaunchKernelGGL((k_seed_pde<CC>), g, dim3(256), 0, e->stream, e->ph, b.x, b.V,
+                                        (const float* const*)e->orth_dev, b.u, b.Hu, e->sums(), b.Ob, d_resid, e->dsc(),
+                                        b.n, b.ld, want_seeds));
+    HIPCHK(e, hipGetLastError());
+    return GPE_OK;
+}
+
+int gpe_step_begin(gpe_engine* e) {
+    if (!e) return GPE_ERR_INVALID;
+    if (e->main.n <= 0) FAIL(e, GPE_ERR_STATE, "step before bind_points");
+    int rc;
+    HIPCHK(e, hipMemsetAsync(e->dbl, 0, (S_COUNT + LS_COUNT + 4) * sizeof(double), e->stream));
+    HIPCHK(e, hipMemsetAsync(e->grad, 0, ((size_t)e->P + GT_COUNT) * sizeof(float), e->stream));
+    if ((rc = mlp_forward(e, e->main, true))) return rc;
+    if ((rc = launch_head_pde(e))) return rc;
+    if (e->cfg.w_sym != 0.f) {
+        if ((rc = mlp_forward(e, e->sym, true))) return rc;
+        hipLaunchKernelGGL(k_head_sym, dim3(cdiv(e->main.n, 256)), dim3(256), 0, e->stream, e->ph, e->sym.O, e->sums(),
+                           e->main.n, e->sym.ld);
+        HIPCHK(e, hipGetLastError());
+    }
+    e->phase = 1;
+    return GPE_OK;
+}
+
+static int bc_terms(gpe_engine* e, bool with_backward) {
+    if (e->bc.n <= 0 || e->cfg.w_bc == 0.f) return GPE_OK;
+    int rc;
+    if ((rc = mlp_forward(e, e->bc, true))) return rc;
+    hipLaunchKernelGGL(k_head_seed_bc, dim3(cdiv(e->bc.n, 256)), dim3(256), 0, e->stream, e->ph, e->base_norm, e->bc.x,
+                       e->bc_target, e->bc.O, e->bc.Ob, e->lsums(), e->bc.n, e->bc.ld);
+    HIPCHK(e, hipGetLastError());
+    if (with_backward) return mlp_backward(e, e->bc);
+    return GPE_OK;
+}
+
+int gpe_step_backward(gpe_engine* e) {
+    if (!e) return GPE_ERR_INVALID;
+    if (e->phase != 1) FAIL(e, GPE_ERR_STATE, "step_backward without step_begin");
+    int rc;
+    if ((rc = launch_seed_pde(e, nullptr, 1))) return rc;
+    if ((rc = mlp_backward(e, e->main))) return rc;
+    if (e->cfg.w_sym != 0.f) {
+        hipLaunchKernelGGL(k_seed_sym, dim3(cdiv(e->main.n, 256)), dim3(256), 0, e->stream, e->ph, e->sym.O, e->sym.Ob,
+                           e->main.n, e->sym.ld);
+        HIPCHK(e, hipGetLastError());
+        if ((rc = mlp_backward(e, e->sym))) return rc;
+    }
+    if ((rc = bc_terms(e, true))) return rc;
+    hipLaunchKernelGGL(k_tail, dim3(1), dim3(1), 0, e->stream, e->grad + e->P, e->dsc());
+    HIPCHK(e, hipGetLastError());
+    e->phase = 2;
+    return GPE_OK;
+}
+
+static double bc_count(gpe_engine* e) { return (e->bc.n > 0 && e->cfg.w_bc != 0.f) ? (double)e->bc.n * e->nd.n_out : 0.0; }
+
+int gpe_step_update(gpe_engine* e) {
+    if (!e) return GPE_ERR_INVALID;
+    if (e->phase != 2) FAIL(e, GPE_ERR_STATE, "step_update without step_backward");
+    hipLaunchKernelGGL(k_update, dim3(1), dim3(1024), 0, e->stream, e->P, e->theta, e->am, e->av, e->grad, e->sums(),
+                       e->lsums(), e->ph, e->oc, e->od, e->hist, e->cap, e->last, bc_count(e), 1);
+    HIPCHK(e, hipGetLastError());
+    e->packed_dirty = true;
+    e->phase = 0;
+    return GPE_OK;
+}
+
+int gpe_exchange_sums(gpe_engine* e, void** p, int64_t* count) {
+    if (!e || !p || !count) return GPE_ERR_INVALID;
+    *p = e->sums(); *count = S_COUNT;
+    return GPE_OK;
+}
+int gpe_exchange_grad(gpe_engine* e, void** p, int64_t* count) {
+    if (!e || !p || !count) return GPE_ERR_INVALID;
+    *p = e->grad; *count = e->P + GT_COUNT;
+    return GPE_OK;
+}
+
+int gpe_read_scalars(gpe_engine* e, gpe_scalars* out) {
+    if (!e || !out) return GPE_ERR_INVALID;
+    HIPCHK(e, hipMemcpyAsync(out, e->last, sizeof *out, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (out->reserved[0] != 0.0) FAIL(e, GPE_ERR_NONFINITE, "non-finite loss or gradient at step %lld; parameters not updated", (long long)out->step + 1);
+    return GPE_OK;
+}
+
+int gpe_read_history(gpe_engine* e, int64_t first, int64_t count, gpe_scalars* out) {
+    if (!e || !out || first < 1 || count < 0) return GPE_ERR_INVALID;
+    if (count > e->cap) FAIL(e, GPE_ERR_INVALID, "history window larger than capacity %d", e->cap);
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    for (int64_t i = 0; i < count;) {
+        int64_t slot = (first - 1 + i) % e->cap;
+        int64_t run = std::min<int64_t>(count - i, e->cap - slot);
+        HIPCHK(e, hipMemcpy(out + i, e->hist + slot, run * sizeof(gpe_scalars), hipMemcpyDeviceToHost));
+        i += run;
+    }
+    return GPE_OK;
+}
+
+int gpe_step(gpe_engine* e, gpe_scalars* out) {
+    int rc;
+    if ((rc = gpe_step_begin(e))) return rc;
+    if ((rc = gpe_step_backward(e))) return rc;
+    if ((rc = gpe_step_update(e))) return rc;
+    if (out) return gpe_read_scalars(e, out);
+    return GPE_OK;
+}
+
+int gpe_run(gpe_engine* e, int64_t n_steps) {
+    for (int64_t i = 0; i < n_steps; ++i) {
+        int rc = gpe_step(e, nullptr);
+        if (rc) return rc;
+    }
+    return GPE_OK;
+}
+
+int gpe_residual(gpe_engine* e, gpe_scalars* out, float* d_psi, float* d_resid) {
+    if (!e || !out) return GPE_ERR_INVALID;
+    if (e->main.n <= 0) FAIL(e, GPE_ERR_STATE, "residual before bind_points");
+    int rc;
+    HIPCHK(e, hipMemsetAsync(e->dbl, 0, (S_COUNT + LS_COUNT + 4) * sizeof(double), e->stream));
+    HIPCHK(e, hipMemsetAsync(e->grad, 0, ((size_t)e->P + GT_COUNT) * sizeof(float), e->stream));
+    if ((rc = mlp_forward(e, e->main, false))) return rc;
+    if ((rc = launch_head_pde(e))) return rc;
+    if (e->cfg.w_sym != 0.f) {
+        if ((rc = mlp_forward(e, e->sym, false))) return rc;
+        hipLaunchKernelGGL(k_head_sym, dim3(cdiv(e->main.n, 256)), dim3(256), 0, e->stream, e->ph, e->sym.O, e->sums(),
+                           e->main.n, e->sym.ld);
+    }
+    if ((rc = launch_seed_pde(e, d_resid, 0))) return rc;
+    if ((rc = bc_terms(e, false))) return rc;
+    if (d_psi) hipLaunchKernelGGL(k_copy_psi, dim3(cdiv(e->main.n, 256)), dim3(256), 0, e->stream, e->main.u, d_psi, e->main.n,
+                                  e->main.ld, e->nd.n_out);
+    hipLaunchKernelGGL(k_tail, dim3(1), dim3(1), 0, e->stream, e->grad + e->P, e->dsc());
+    hipLaunchKernelGGL(k_update, dim3(1), dim3(1024), 0, e->stream, e->P, e->theta, e->am, e->av, e->grad, e->sums(),
+                       e->lsums(), e->ph, e->oc, e->od, e->hist, e->cap, e->last, bc_count(e), 0);
+    HIPCHK(e, hipGetLastError());
+    e->phase = 0;
+    HIPCHK(e, hipMemcpyAsync(out, e->last, sizeof *out, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return GPE_OK;
+}
+
+int gpe_set_gamma(gpe_engine* e, float g) { if (!e) return GPE_ERR_INVALID; e->cfg.gamma = g; fill_phys(e); return GPE_OK; }
+int gpe_set_power(gpe_engine* e, int p) {
+    if (!e) return GPE_ERR_INVALID;
+    if (p < 1 || p > 32) FAIL(e, GPE_ERR_INVALID, "power p must be in [1,32]");
+    e->cfg.p = p; fill_phys(e); return GPE_OK;
+}
+int gpe_set_perturb_scale(gpe_engine* e, float s) { if (!e) return GPE_ERR_INVALID; e->cfg.perturb_scale = s; fill_phys(e); return GPE_OK; }
+int gpe_set_n_global(gpe_engine* e, int64_t n) { if (!e) return GPE_ERR_INVALID; e->cfg.n_global = n; fill_phys(e); return GPE_OK; }
+int gpe_set_lr(gpe_engine* e, float lr) {
+    if (!e) return GPE_ERR_INVALID;
+    OptDev h;
+    HIPCHK(e, hipMemcpyAsync(&h, e->od, sizeof h, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    h.lr = lr; h.lr0 = lr;
+    HIPCHK(e, hipMemcpyAsync(e->od, &h, sizeof h, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return GPE_OK;
+}
+
+int gpe_step_cost(const gpe_engine* e, double* flops_per_point, double* hbm_bytes_per_point) {
+    if (!e) return GPE_ERR_INVALID;
+    // F_fwd = 2 d H + (1+2d) [2 H^2 (L-1) + 2 H out] (+ activations), F_step = 3 F_fwd ; B_mat = 2 (1+2d) H L 4
+    const int d = e->nd.dim, L = e->nd.n_lin - 1, H = e->nd.width[1], no = e->nd.n_out;
+    const double C = 1 + 2 * d;
+    double gemm = 2.0 * d * H + C * (2.0 * H * H * (L - 1) + 2.0 * H * no);
+    double act = (double)H * L * (3 + 5 * d);
+    if (flops_per_point) *flops_per_point = 3.0 * (gemm + act);
+    if (hbm_bytes_per_point) *hbm_bytes_per_point = 2.0 * C * H * L * 4.0;
+    return GPE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,259 @@
+// gpe_head.h -- physics kernels shared by both MLP kernel sets: NN output jets -> (u, Hu, sums),
+// sums -> lambda, residual, seeds (adjoint of the NN output jets); boundary and symmetry terms.
+//
+// Layout of the output jets O and their adjoint Ob: [C][n_out][ld] (point index contiguous).
+// Reference: pde_loss refine/harmonic_pinn_simulation.py:146-196 (nb c6:L81-127), boundary_loss :198-210,
+// normalization_loss :212-217, symmetry_loss nb c6:L137-155; 2D Laplacian template src/gross_pitaevskii_2D.py:183-195.
+#pragma once
+#include "gpe_common.h"
+
+// u-jets (value, first, second derivatives) of component o at point m from NN output jets.
+template <int C>
+GPE_DEV void load_u_jets(const Phys& ph, const float* __restrict__ O, int64_t ld, int64_t m, int o,
+                         const float* xv, float base_norm, float* U /*[C]*/) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) U[c] = ph.perturb_scale * O[((int64_t)c * ph.n_out + o) * ld + m];
+    if (ph.base_mode >= 0 && C == 3) {
+        float phi, p1, p2;
+        hermite_base(xv[0], ph.base_mode, ph.base_deriv, base_norm, phi, p1, p2);
+        U[0] += phi; U[1] += p1; U[2] += p2;
+    }
+}
+
+// ---- phase 1: u, Hu per point; block partial sums into sums[] (double atomics) ---------------------
+template <int C>
+__global__ __launch_bounds__(256) void k_head_pde(Phys ph, float base_norm, const float* __restrict__ x,
+                                                  const float* __restrict__ Vpre, const float* __restrict__ O,
+                                                  const float* const* __restrict__ orth, float* __restrict__ u_out,
+                                                  float* __restrict__ Hu_out, double* __restrict__ sums, int64_t N,
+                                                  int64_t ld) {
+    constexpr int D = (C - 1) / 2;
+    __shared__ double red[4];
+    int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double num = 0.0, den = 0.0, so[GPE_MAX_ORTH] = {0.0, 0.0, 0.0, 0.0};
+    if (m < N) {
+        float xv[3] = {0.f, 0.f, 0.f};
+        for (int k = 0; k < ph.dim; ++k) xv[k] = x[m * ph.dim + k];
+        float V = potential_at(ph, xv, Vpre, m);
+        float U[2][C];
+        for (int o = 0; o < ph.n_out; ++o) load_u_jets<C>(ph, O, ld, m, o, xv, base_norm, U[o]);
+        float Hu[2] = {0.f, 0.f};
+        if (!ph.complex_psi) {
+            float u = U[0][0], lap = 0.f;
+#pragma unroll
+            for (int j = 0; j < D; ++j) lap += U[0][1 + D + j];
+            float inter = ph.abs_power ? ph.gamma * ipowf(fabsf(u), ph.p - 1) * u : ph.gamma * ipowf(u, ph.p);
+            Hu[0] = -ph.kin * lap + V * u + inter;
+        } else {
+            float ur = U[0][0], ui = U[1][0];
+            float rho = ur * ur + ui * ui;
+            float lr = 0.f, li = 0.f;
+#pragma unroll
+            for (int j = 0; j < D; ++j) { lr += U[0][1 + D + j]; li += U[1][1 + D + j]; }
+            Hu[0] = -ph.kin * lr + V * ur + ph.gamma * rho * ur;
+            Hu[1] = -ph.kin * li + V * ui + ph.gamma * rho * ui;
+            if (ph.omega_rot != 0.f && D >= 2) {
+                float Dr = xv[0] * U[0][2] - xv[1] * U[0][1];
+                float Di = xv[0] * U[1][2] - xv[1] * U[1][1];
+                Hu[0] += -ph.omega_rot * Di;
+                Hu[1] += ph.omega_rot * Dr;
+            }
+        }
+        for (int o = 0; o < ph.n_out; ++o) {
+            float u = U[o][0];
+            u_out[(int64_t)o * ld + m] = u;
+            Hu_out[(int64_t)o * ld + m] = Hu[o];
+            num += (double)(u * Hu[o]);
+            den += (double)(u * u);
+        }
+        for (int j = 0; j < ph.n_orth; ++j) so[j] = (double)(orth[j][m] * U[0][0]);
+    }
+    double r = block_sum_256(num, red);
+    if (threadIdx.x == 0) atomicAdd(&sums[S_NUM], r);
+    r = block_sum_256(den, red);
+    if (threadIdx.x == 0) atomicAdd(&sums[S_DEN], r);
+    for (int j = 0; j < ph.n_orth; ++j) {
+        r = block_sum_256(so[j], red);
+        if (threadIdx.x == 0) atomicAdd(&sums[S_ORTH0 + j], r);
+    }
+}
+
+// ---- phase 2: residual + seeds -------------------------------------------------------------------
+// lambda = num/den (global sums), r = Hu - lambda u, sum r^2 -> gtail[GT_SUM_R2]; Ob = dLoss/dO.
+template <int C>
+__global__ __launch_bounds__(256) void k_seed_pde(Phys ph, const float* __restrict__ x, const float* __restrict__ Vpre,
+                                                  const float* const* __restrict__ orth,
+                                                  const float* __restrict__ u_in, const float* __restrict__ Hu_in,
+                                                  const double* __restrict__ sums, float* __restrict__ Ob,
+                                                  float* __restrict__ resid_out, double* __restrict__ sum_r2, int64_t N,
+                                                  int64_t ld, int want_seeds) {
+    constexpr int D = (C - 1) / 2;
+    __shared__ double red[4];
+    int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double sr2 = 0.0;
+    if (m < N) {
+        float lam = (float)(sums[S_NUM] / sums[S_DEN]);
+        float I = (float)sums[S_DEN] * ph.dx;
+        float xv[3] = {0.f, 0.f, 0.f};
+        for (int k = 0; k < ph.dim; ++k) xv[k] = x[m * ph.dim + k];
+        float V = potential_at(ph, xv, Vpre, m);
+        float u[2] = {0.f, 0.f}, r[2] = {0.f, 0.f}, rb[2] = {0.f, 0.f};
+        float cr = (float)(2.0 * (double)ph.w_pde / ph.n_global);
+        for (int o = 0; o < ph.n_out; ++o) {
+            u[o] = u_in[(int64_t)o * ld + m];
+            r[o] = Hu_in[(int64_t)o * ld + m] - lam * u[o];
+            rb[o] = cr * r[o];
+            sr2 += (double)(r[o] * r[o]);
+            if (resid_out) resid_out[m * ph.n_out + o] = r[o];
+        }
+        if (want_seeds) {
+            float ub[2] = {0.f, 0.f};
+            if (!ph.complex_psi) {
+                float dint = ph.abs_power ? ph.gamma * (float)ph.p * ipowf(fabsf(u[0]), ph.p - 1)
+                                          : ph.gamma * (float)ph.p * ipowf(u[0], ph.p - 1);
+                ub[0] = rb[0] * (V + dint - lam);
+            } else {
+                float ur = u[0], ui = u[1], rho = ur * ur + ui * ui, g = ph.gamma;
+                ub[0] = rb[0] * (V + g * (rho + 2.f * ur * ur) - lam) + rb[1] * (2.f * g * ur * ui);
+                ub[1] = rb[1] * (V + g * (rho + 2.f * ui * ui) - lam) + rb[0] * (2.f * g * ur * ui);
+            }
+            float cn = ph.w_norm * 4.0f * (I - 1.0f) * ph.dx;
+            for (int o = 0; o < ph.n_out; ++o) ub[o] += cn * u[o];
+            for (int j = 0; j < ph.n_orth; ++j) {
+                float Oj = (float)(sums[S_ORTH0 + j]) * ph.dx;
+                ub[0] += ph.w_orth * 2.0f * Oj * ph.dx * orth[j][m];
+            }
+            float sc = ph.perturb_scale;
+            for (int o = 0; o < ph.n_out; ++o) {
+                float Ub[C];
+                Ub[0] = ub[o];
+#pragma unroll
+                for (int j = 0; j < D; ++j) { Ub[1 + j] = 0.f; Ub[1 + D + j] = -ph.kin * rb[o]; }
+                if (ph.complex_psi && ph.omega_rot != 0.f && D >= 2) {
+                    float Om = ph.omega_rot;
+                    if (o == 1) { Ub[2] += -Om * xv[0] * rb[0]; Ub[1] += Om * xv[1] * rb[0]; }
+                    else        { Ub[2] += Om * xv[0] * rb[1];  Ub[1] += -Om * xv[1] * rb[1]; }
+                }
+#pragma unroll
+                for (int c = 0; c < C; ++c) Ob[((int64_t)c * ph.n_out + o) * ld + m] = sc * Ub[c];
+            }
+        }
+    }
+    double t = block_sum_256(sr2, red);
+    if (threadIdx.x == 0) atomicAdd(sum_r2, t);
+}
+
+// ---- boundary batch (value only): e = base + s*NN - target; sum e^2; Ob = w_bc*2/(cnt) * e * s / world ------
+__global__ __launch_bounds__(256) void k_head_seed_bc(Phys ph, float base_norm, const float* __restrict__ xb,
+                                                      const float* __restrict__ target, const float* __restrict__ O,
+                                                      float* __restrict__ Ob, double* __restrict__ lsums, int64_t nb,
+                                                      int64_t ld) {
+    __shared__ double red[4];
+    int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double se = 0.0;
+    if (m < nb) {
+        float cnt = (float)(nb * ph.n_out);
+        for (int o = 0; o < ph.n_out; ++o) {
+            float e = ph.bc_nn_scale * O[(int64_t)o * ld + m];
+            if (ph.base_mode >= 0 && o == 0) {
+                float phi, p1, p2;
+                hermite_base(xb[m * ph.dim], ph.base_mode, ph.base_deriv, base_norm, phi, p1, p2);
+                e += phi;
+            }
+            if (target) e -= target[m * ph.n_out + o];
+            se += (double)(e * e);
+            Ob[(int64_t)o * ld + m] = ph.w_bc * 2.0f / cnt * e * ph.bc_nn_scale * ph.inv_world;
+        }
+    }
+    double t = block_sum_256(se, red);
+    if (threadIdx.x == 0) atomicAdd(&lsums[LS_BC_SE2], t);
+}
+
+// ---- symmetry batch: points [x ; -x] (2N, value only): diff = o(x) - sign*o(-x) ----------------------------
+__global__ __launch_bounds__(256) void k_head_sym(Phys ph, const float* __restrict__ O, double* __restrict__ sums,
+                                                  int64_t N, int64_t ld) {
+    __shared__ double red[4];
+    int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double s = 0.0;
+    if (m < N) {
+        for (int o = 0; o < ph.n_out; ++o) {
+            float d = O[(int64_t)o * ld + m] - ph.sym_sign * O[(int64_t)o * ld + N + m];
+            s += (double)(d * d);
+        }
+    }
+    double t = block_sum_256(s, red);
+    if (threadIdx.x == 0) atomicAdd(&sums[S_SYM], t);
+}
+
+__global__ __launch_bounds__(256) void k_seed_sym(Phys ph, const float* __restrict__ O, float* __restrict__ Ob,
+                                                  int64_t N, int64_t ld) {
+    int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m < N) {
+        float c = (float)(2.0 * (double)ph.w_sym / ph.n_global);
+        for (int o = 0; o < ph.n_out; ++o) {
+            float d = O[(int64_t)o * ld + m] - ph.sym_sign * O[(int64_t)o * ld + N + m];
+            Ob[(int64_t)o * ld + m] = c * d;
+            Ob[(int64_t)o * ld + N + m] = -ph.sym_sign * c * d;
+        }
+    }
+}
+
+// x -> [x ; -x]
+__global__ void k_make_sym_points(const float* __restrict__ x, float* __restrict__ xs, int64_t N, int dim) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < N * dim) { float v = x[i]; xs[i] = v; xs[N * dim + i] = -v; }
+}
+
+// out [n,out] row-major from O[0][o][m]
+__global__ void k_copy_values(const float* __restrict__ O, float* __restrict__ out, int64_t N, int64_t ld, int n_out) {
+    int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m < N) for (int o = 0; o < n_out; ++o) out[m * n_out + o] = O[(int64_t)o * ld + m];
+}
+// jets [C][n][out] from O [C][out][ld]
+__global__ void k_copy_jets(const float* __restrict__ O, float* __restrict__ jets, int64_t N, int64_t ld, int n_out, int C) {
+    int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m < N) for (int c = 0; c < C; ++c) for (int o = 0; o < n_out; ++o)
+        jets[((int64_t)c * N + m) * n_out + o] = O[((int64_t)c * n_out + o) * ld + m];
+}
+__global__ void k_copy_psi(const float* __restrict__ u, float* __restrict__ out, int64_t N, int64_t ld, int n_out) {
+    int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m < N) for (int o = 0; o < n_out; ++o) out[m * n_out + o] = u[(int64_t)o * ld + m];
+}
+
+// eval path: u = base + scale*NN ; sum u^2
+__global__ __launch_bounds__(256) void k_eval_u(Phys ph, float base_norm, const float* __restrict__ x,
+                                                const float* __restrict__ O, float* __restrict__ u, double* __restrict__ acc,
+                                                int64_t N, int64_t ld) {
+    __shared__ double red[4];
+    int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double s = 0.0;
+    if (m < N) {
+        for (int o = 0; o < ph.n_out; ++o) {
+            float v = ph.perturb_scale * O[(int64_t)o * ld + m];
+            if (ph.base_mode >= 0 && o == 0) {
+                float phi, p1, p2;
+                hermite_base(x[m * ph.dim], ph.base_mode, ph.base_deriv, base_norm, phi, p1, p2);
+                v += phi;
+            }
+            u[(int64_t)o * ld + m] = v;
+            s += (double)(v * v);
+        }
+    }
+    double t = block_sum_256(s, red);
+    if (threadIdx.x == 0) atomicAdd(acc, t);
+}
+__global__ void k_eval_finish(const float* __restrict__ u, const double* __restrict__ acc, float dx, int abs_flag,
+                              float* __restrict__ u_out, float* __restrict__ dens, int64_t N, int64_t ld, int n_out) {
+    int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m < N) {
+        float nrm = sqrtf((float)(*acc) * dx);
+        float d = 0.f;
+        for (int o = 0; o < n_out; ++o) {
+            float v = u[(int64_t)o * ld + m] / nrm;
+            if (abs_flag) v = fabsf(v);
+            if (u_out) u_out[m * n_out + o] = v;
+            d += v * v;
+        }
+        if (dens) dens[m] = d;
+    }
+}

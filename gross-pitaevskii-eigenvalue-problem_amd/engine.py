@@ -1,0 +1,342 @@
+"""Host-side handle on the HIP engine (libgpe_hip.so).  PyTorch-ROCm tensors are used as device storage
+and for torch.distributed (RCCL) only -- every number on the hot path is produced by the HIP kernels.
+
+Replaces, for the hot path: the model/optimizer/scheduler objects and the epoch body of
+refine/harmonic_pinn_simulation.py:295-361 and Gross_Pitaevskii_1D_power_Test.ipynb c10:L63-103.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _capi as capi
+
+
+class GPEError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"[gpe status {code}] {msg}")
+        self.code = code
+
+
+@dataclass
+class GPEConfig:
+    """Python twin of include/gpe_hip.h:gpe_config (see the header for the reference citation of every field)."""
+    layers: Sequence[int]
+    activation: int = capi.ACT_TANH
+    complex_psi: bool = False
+    kinetic_coeff: float = 0.5
+    potential: int = capi.POT_HARMONIC
+    pot_scale: float = 0.5
+    omega: Sequence[float] = (1.0, 1.0, 1.0)
+    pot_a: float = 0.0
+    pot_v0: float = 1.0
+    pot_k: float = 2.0 * np.pi / 5.0
+    omega_rot: float = 0.0
+    gamma: float = 0.0
+    p: int = 3
+    abs_power: bool = False
+    base_mode: int = -1
+    base_deriv: int = 0
+    perturb_scale: float = 1.0
+    bc_nn_scale: float = 1.0
+    w_pde: float = 1.0
+    w_bc: float = 10.0
+    w_norm: float = 20.0
+    w_sym: float = 0.0
+    w_orth: float = 0.0
+    sym_sign: float = 1.0
+    dx: float = 1.0
+    n_global: int = 0
+    lr: float = 1e-3
+    beta1: float = 0.9
+    beta2: float = 0.999
+    eps: float = 1e-8
+    clip_norm: float = 1.0
+    sched: int = capi.SCHED_CONST
+    T_0: float = 200.0
+    T_mult: float = 2.0
+    eta_min: float = 1e-6
+    factor: float = 0.5
+    patience: int = 100
+    min_lr: float = 1e-5
+    threshold: float = 1e-4
+    path: int = capi.PATH_AUTO
+    world_size: int = 1
+    history_capacity: int = 0
+
+    def to_c(self) -> capi.gpe_config:
+        c = capi.gpe_config()
+        c.abi_version = capi.GPE_ABI_VERSION
+        layers = [int(v) for v in self.layers]
+        if len(layers) > capi.GPE_MAX_LAYERS:
+            raise ValueError(f"at most {capi.GPE_MAX_LAYERS} layer entries")
+        c.n_layers = len(layers)
+        for i, v in enumerate(layers):
+            c.layers[i] = v
+        om = list(self.omega) + [1.0] * 3
+        for i in range(3):
+            c.omega[i] = float(om[i])
+        for name in ("activation", "potential", "p", "base_mode", "base_deriv", "sched", "patience", "path",
+                     "world_size", "history_capacity", "n_global"):
+            setattr(c, name, int(getattr(self, name)))
+        c.complex_psi = int(bool(self.complex_psi))
+        c.abs_power = int(bool(self.abs_power))
+        for name in ("kinetic_coeff", "pot_scale", "pot_a", "pot_v0", "pot_k", "omega_rot", "gamma", "perturb_scale",
+                     "bc_nn_scale", "w_pde", "w_bc", "w_norm", "w_sym", "w_orth", "sym_sign", "dx", "lr", "beta1",
+                     "beta2", "eps", "clip_norm", "T_0", "T_mult", "eta_min", "factor", "min_lr", "threshold"):
+            setattr(c, name, float(getattr(self, name)))
+        return c
+
+    @property
+    def dim(self):
+        return int(self.layers[0])
+
+    @property
+    def n_out(self):
+        return int(self.layers[-1])
+
+    @property
+    def n_channels(self):
+        return 1 + 2 * self.dim
+
+
+def _check_dev_f32(t: torch.Tensor, name: str):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError(f"{name} must be a contiguous float32 tensor on the GPU")
+
+
+class Engine:
+    """One engine per process per GPU.  The HIP extension is mandatory (no fallback)."""
+
+    def __init__(self, cfg: GPEConfig, device: Optional[int] = None, use_torch_stream: bool = True):
+        if not torch.cuda.is_available():
+            raise GPEError(capi.GPE_ERR_HIP, "no GPU visible: the GPE engine has no CPU fallback")
+        self.lib = capi.load()
+        self.cfg = cfg
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        torch.cuda.set_device(self.device)
+        # kernels are enqueued on torch's current stream so that they are ordered with RCCL collectives
+        stream = torch.cuda.current_stream(self.device).cuda_stream if use_torch_stream else 0
+        self._h = C.c_void_p()
+        ccfg = cfg.to_c()
+        rc = self.lib.gpe_create(C.byref(ccfg), self.device, C.c_void_p(stream), C.byref(self._h))
+        if rc != capi.GPE_OK:
+            msg = self.lib.gpe_last_error(None)
+            code = capi.GPE_ERR_INVALID if rc == capi.GPE_ERR_INVALID else rc
+            err = msg.decode() if msg else "gpe_create failed"
+            if rc == capi.GPE_ERR_INVALID:
+                raise ValueError(err)          # the reference raises ValueError for bad problem descriptions
+            raise GPEError(code, err)
+        self.n_params = int(self.lib.gpe_param_count(self._h))
+        self._keep = {}
+        # caller-owned exchange buffers (so torch.distributed can all-reduce them in place)
+        nd = int(self.lib.gpe_exchange_dbl_count())
+        self._xdbl = torch.zeros(nd, dtype=torch.float64, device=f"cuda:{self.device}")
+        self._xgrad = torch.zeros(self.n_params + 4, dtype=torch.float32, device=f"cuda:{self.device}")
+        self._chk(self.lib.gpe_use_external_exchange(self._h, C.c_void_p(self._xdbl.data_ptr()), nd,
+                                                     C.c_void_p(self._xgrad.data_ptr()), self._xgrad.numel()))
+        p, n = C.c_void_p(), C.c_int64()
+        self._chk(self.lib.gpe_exchange_sums(self._h, C.byref(p), C.byref(n)))
+        assert p.value == self._xdbl.data_ptr()
+        self._sums_view = self._xdbl[: n.value]
+
+    # ---- plumbing -----------------------------------------------------------------------------
+    def _chk(self, rc):
+        if rc != capi.GPE_OK:
+            msg = self.lib.gpe_last_error(self._h)
+            raise GPEError(rc, msg.decode() if msg else "?")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.gpe_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def active_path(self) -> int:
+        return int(self.lib.gpe_active_path(self._h))
+
+    # ---- parameters ---------------------------------------------------------------------------------
+    def set_params(self, flat):
+        a = np.ascontiguousarray(np.asarray(flat, dtype=np.float32).ravel())
+        self._chk(self.lib.gpe_set_params(self._h, a.ctypes.data_as(C.c_void_p), a.size))
+
+    def get_params(self) -> np.ndarray:
+        a = np.empty(self.n_params, dtype=np.float32)
+        self._chk(self.lib.gpe_get_params(self._h, a.ctypes.data_as(C.c_void_p), a.size))
+        return a
+
+    def get_grad(self) -> np.ndarray:
+        a = np.empty(self.n_params, dtype=np.float32)
+        self._chk(self.lib.gpe_get_grad(self._h, a.ctypes.data_as(C.c_void_p), a.size))
+        return a
+
+    def get_adam_state(self):
+        m = np.empty(self.n_params, dtype=np.float32)
+        v = np.empty(self.n_params, dtype=np.float32)
+        step = C.c_int64()
+        self._chk(self.lib.gpe_get_adam_state(self._h, m.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p),
+                                              m.size, C.byref(step)))
+        return m, v, int(step.value)
+
+    def set_adam_state(self, m, v, step):
+        m = np.ascontiguousarray(m, dtype=np.float32)
+        v = np.ascontiguousarray(v, dtype=np.float32)
+        self._chk(self.lib.gpe_set_adam_state(self._h, m.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p),
+                                              m.size, int(step)))
+
+    def reset_optimizer(self, lr: float):
+        self._chk(self.lib.gpe_reset_optimizer(self._h, float(lr)))
+
+    # ---- data ---------------------------------------------------------------------------------------------
+    def _to_dev(self, a, name):
+        if isinstance(a, torch.Tensor):
+            t = a.to(device=f"cuda:{self.device}", dtype=torch.float32).contiguous()
+        else:
+            t = torch.as_tensor(np.asarray(a, dtype=np.float32), device=f"cuda:{self.device}").contiguous()
+        _check_dev_f32(t, name)
+        return t
+
+    def bind_points(self, x, V=None):
+        x = self._to_dev(x, "x")
+        if x.dim() != 2 or x.shape[1] != self.cfg.dim:
+            raise ValueError(f"x must be [N,{self.cfg.dim}]")
+        Vt = None if V is None else self._to_dev(V, "V").reshape(-1)
+        self._keep["x"], self._keep["V"] = x, Vt
+        self._chk(self.lib.gpe_bind_points(self._h, C.c_void_p(x.data_ptr()), x.shape[0],
+                                           C.c_void_p(Vt.data_ptr()) if Vt is not None else None))
+        self.n_local = int(x.shape[0])
+
+    def bind_boundary(self, xb, target=None):
+        if xb is None:
+            self._chk(self.lib.gpe_bind_boundary(self._h, None, 0, None))
+            return
+        xb = self._to_dev(xb, "xb")
+        tg = None if target is None else self._to_dev(target, "target")
+        self._keep["xb"], self._keep["tg"] = xb, tg
+        self._chk(self.lib.gpe_bind_boundary(self._h, C.c_void_p(xb.data_ptr()), xb.shape[0],
+                                             C.c_void_p(tg.data_ptr()) if tg is not None else None))
+
+    def bind_orth(self, k: int, psi_k):
+        t = None if psi_k is None else self._to_dev(psi_k, "psi_k").reshape(-1)
+        self._keep[f"orth{k}"] = t
+        self._chk(self.lib.gpe_bind_orth(self._h, int(k), C.c_void_p(t.data_ptr()) if t is not None else None))
+
+    # ---- forward-only -----------------------------------------------------------------------------------------
+    def forward(self, x) -> torch.Tensor:
+        x = self._to_dev(x, "x")
+        out = torch.empty((x.shape[0], self.cfg.n_out), dtype=torch.float32, device=x.device)
+        self._chk(self.lib.gpe_forward(self._h, C.c_void_p(x.data_ptr()), x.shape[0], C.c_void_p(out.data_ptr())))
+        return out
+
+    def forward_jets(self, x) -> torch.Tensor:
+        x = self._to_dev(x, "x")
+        out = torch.empty((self.cfg.n_channels, x.shape[0], self.cfg.n_out), dtype=torch.float32, device=x.device)
+        self._chk(self.lib.gpe_forward_jets(self._h, C.c_void_p(x.data_ptr()), x.shape[0], C.c_void_p(out.data_ptr())))
+        return out
+
+    def residual(self, want_fields: bool = True):
+        sc = capi.gpe_scalars()
+        psi = res = None
+        if want_fields:
+            psi = torch.empty((self.n_local, self.cfg.n_out), dtype=torch.float32, device=f"cuda:{self.device}")
+            res = torch.empty_like(psi)
+        self._chk(self.lib.gpe_residual(self._h, C.byref(sc), C.c_void_p(psi.data_ptr()) if want_fields else None,
+                                        C.c_void_p(res.data_ptr()) if want_fields else None))
+        return sc.as_dict(), psi, res
+
+    def eval_density(self, x, dx: float, abs_flag: bool = False):
+        x = self._to_dev(x, "x")
+        u = torch.empty((x.shape[0], self.cfg.n_out), dtype=torch.float32, device=x.device)
+        dens = torch.empty((x.shape[0],), dtype=torch.float32, device=x.device)
+        self._chk(self.lib.gpe_eval_density(self._h, C.c_void_p(x.data_ptr()), x.shape[0], float(dx), int(abs_flag),
+                                            C.c_void_p(u.data_ptr()), C.c_void_p(dens.data_ptr())))
+        return u, dens
+
+    # ---- training ---------------------------------------------------------------------------------------------------
+    def step(self) -> dict:
+        sc = capi.gpe_scalars()
+        self._chk(self.lib.gpe_step(self._h, C.byref(sc)))
+        return sc.as_dict()
+
+    def run(self, n_steps: int):
+        """n_steps steps enqueued back to back; no host synchronisation."""
+        self._chk(self.lib.gpe_run(self._h, int(n_steps)))
+
+    def step_begin(self):
+        self._chk(self.lib.gpe_step_begin(self._h))
+
+    def step_backward(self):
+        self._chk(self.lib.gpe_step_backward(self._h))
+
+    def step_update(self):
+        self._chk(self.lib.gpe_step_update(self._h))
+
+    @property
+    def exchange_sums(self) -> torch.Tensor:
+        """float64 device tensor (view) to all-reduce(sum) between step_begin and step_backward."""
+        return self._sums_view
+
+    @property
+    def exchange_grad(self) -> torch.Tensor:
+        """float32 device tensor [P+4] to all-reduce(sum) between step_backward and step_update."""
+        return self._xgrad
+
+    def step_distributed(self, group=None, sync: bool = False):
+        """One data-parallel step: every rank holds a shard of the collocation points."""
+        import torch.distributed as dist
+        self.step_begin()
+        dist.all_reduce(self._sums_view, op=dist.ReduceOp.SUM, group=group)
+        self.step_backward()
+        dist.all_reduce(self._xgrad, op=dist.ReduceOp.SUM, group=group)
+        self.step_update()
+        if sync:
+            return self.read_scalars()
+        return None
+
+    def synchronize(self):
+        self._chk(self.lib.gpe_synchronize(self._h))
+
+    def read_scalars(self) -> dict:
+        sc = capi.gpe_scalars()
+        self._chk(self.lib.gpe_read_scalars(self._h, C.byref(sc)))
+        return sc.as_dict()
+
+    def read_history(self, first_step: int, count: int):
+        arr = (capi.gpe_scalars * count)()
+        self._chk(self.lib.gpe_read_history(self._h, int(first_step), int(count), arr))
+        return [a.as_dict() for a in arr]
+
+    # ---- continuation knobs --------------------------------------------------------------------------------------------
+    def set_gamma(self, g: float):
+        self.cfg.gamma = float(g)
+        self._chk(self.lib.gpe_set_gamma(self._h, float(g)))
+
+    def set_power(self, p: int):
+        self.cfg.p = int(p)
+        self._chk(self.lib.gpe_set_power(self._h, int(p)))
+
+    def set_lr(self, lr: float):
+        self._chk(self.lib.gpe_set_lr(self._h, float(lr)))
+
+    def set_perturb_scale(self, s: float):
+        self.cfg.perturb_scale = float(s)
+        self._chk(self.lib.gpe_set_perturb_scale(self._h, float(s)))
+
+    def set_n_global(self, n: int):
+        self.cfg.n_global = int(n)
+        self._chk(self.lib.gpe_set_n_global(self._h, int(n)))
+
+    def step_cost(self):
+        f, b = C.c_double(), C.c_double()
+        self._chk(self.lib.gpe_step_cost(self._h, C.byref(f), C.byref(b)))
+        return f.value, b.value

@@ -1,0 +1,179 @@
+/*
+ * gpe_hip.h -- C ABI of libgpe_hip.so: the MI355X (gfx950) engine for the Gross-Pitaevskii
+ * eigenvalue-residual PINN training step.
+ *
+ * The reference (LevBahn/Gross-Pitaevskii-Eigenvalue-problem) has no FFI for this path: it is a set of
+ * Python methods on torch tensors.  Each entry point below names the reference code it replaces
+ * (paths relative to /root/reference; "refine/" = Gross-Pitaevskii/src/final/refine/,
+ * "nb cN:Lm" = Gross_Pitaevskii_1D_power_Test.ipynb code cell N, line m).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.  d_* pointers are DEVICE pointers
+ *     (e.g. tensor.data_ptr() of a PyTorch-ROCm tensor used as storage); h_* are host pointers.
+ *   - Every function returns GPE_OK (0) or a negative gpe_status; gpe_last_error() gives the text.
+ *     No exception crosses the ABI.
+ *   - A handle is single-device and not thread-safe.  One process per GPU; data-parallel exchange is
+ *     done by the caller (RCCL through torch.distributed) on the two device buffers exposed by
+ *     gpe_exchange_sums() / gpe_exchange_grad() between the three phases of a step.
+ *   - All kernels run on the stream given at gpe_create() (NULL = the legacy default stream).
+ *   - Parameters are one flat fp32 vector in torch state_dict order:
+ *       network.0.weight [out,in] row-major, network.0.bias, network.2.weight, ...
+ *     (refine/harmonic_pinn_simulation.py:84-93).
+ *   - Derivative "jets": channel 0 = value, 1..d = d/dx_k, d+1..2d = d2/dx_k^2 (C = 1+2d channels).
+ */
+#ifndef GPE_HIP_H
+#define GPE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPE_ABI_VERSION 1
+#define GPE_MAX_LAYERS 12 /* entries of layers[]: [d, H_1, ..., H_L, out] */
+#define GPE_MAX_ORTH 4
+#define GPE_MAX_DIM 3
+
+typedef enum gpe_status {
+    GPE_OK = 0,
+    GPE_ERR_INVALID = -1,     /* bad argument / unsupported configuration (ValueError in the reference: refine/harmonic_pinn_simulation.py:143) */
+    GPE_ERR_HIP = -2,         /* HIP runtime error */
+    GPE_ERR_NONFINITE = -3,   /* loss or gradient not finite; parameters were NOT updated */
+    GPE_ERR_STATE = -4,       /* call sequence error (e.g. step before bind_points) */
+    GPE_ERR_NOMEM = -5
+} gpe_status;
+
+enum { GPE_ACT_TANH = 0, GPE_ACT_TANH_PLUS1 = 1 };                         /* nb c6:L38 ; refine/harmonic_pinn_simulation.py:41-49 */
+enum { GPE_POT_HARMONIC = 0, GPE_POT_GAUSSIAN = 1, GPE_POT_PERIODIC = 2,   /* nb c6:L63-79 ; refine/...:136-144 */
+       GPE_POT_PRECOMPUTED = 3, GPE_POT_NONE = 4 };
+enum { GPE_SCHED_CONST = 0, GPE_SCHED_COSINE_LOSS = 1, GPE_SCHED_PLATEAU = 2 }; /* refine/...:312-314,361 (quirk Q4) ; nb c10:L76-78,L103 */
+enum { GPE_PATH_AUTO = 0, GPE_PATH_GENERIC = 1, GPE_PATH_FUSED = 2 };
+
+typedef struct gpe_engine gpe_engine; /* opaque */
+
+/* Problem + optimiser description.  Mirrors the literals of refine/harmonic_pinn_simulation.py:963-1009 and
+ * nb c20/c22, and the constructor arguments of GrossPitaevskiiPINN (refine/...:57 ; nb c6:L6). */
+typedef struct gpe_config {
+    int32_t abi_version;          /* = GPE_ABI_VERSION */
+    int32_t n_layers;             /* entries used in layers[] */
+    int32_t layers[GPE_MAX_LAYERS];
+    int32_t activation;           /* GPE_ACT_* */
+    int32_t complex_psi;          /* 1: layers[last]==2, psi = out0 + i*out1 */
+    float kinetic_coeff;          /* c in -c*laplacian: 1 (refine/...:181) or 0.5 (nb c6:L113) */
+    int32_t potential;            /* GPE_POT_* */
+    float pot_scale;              /* harmonic: V = pot_scale * sum_k (omega[k]*x_k)^2 */
+    float omega[GPE_MAX_DIM];
+    float pot_a, pot_v0, pot_k;   /* gaussian centre; periodic depth, wave number */
+    float omega_rot;              /* rotation frequency Omega: -Omega*L_z psi (complex psi, dim>=2) */
+    float gamma;                  /* interaction strength (refine/...:184) */
+    int32_t p;                    /* nonlinearity power: gamma*u^p */
+    int32_t abs_power;            /* 1: gamma*|u|^(p-1)*u */
+    int32_t base_mode;            /* -1 none; n>=0: u = phi_n(x) + perturbation (refine/...:127-134) */
+    int32_t base_deriv;           /* 0 exact base derivatives; 1 notebook quirk Q8 (H_n constant, nb c6:L45-47) */
+    float perturb_scale;          /* q/normal_const (refine/...:333-340); 1 for the notebook surface */
+    float bc_nn_scale;            /* NN scale inside boundary_loss (quirk Q7: 1.0, refine/...:202-206) */
+    float w_pde, w_bc, w_norm, w_sym, w_orth;   /* refine/...:347,355 ; nb c10:L97 */
+    float sym_sign;               /* +1 even mode, -1 odd mode (nb c6:L150-153) */
+    float dx;                     /* quadrature weight of normalization_loss (refine/...:212-217) */
+    int64_t n_global;             /* N of the means, over ALL ranks (0: use the bound local count) */
+    /* optimiser: torch.optim.Adam defaults + clip_grad_norm_ (refine/...:309,359-360) */
+    float lr, beta1, beta2, eps, clip_norm;   /* clip_norm <= 0: no clipping */
+    int32_t sched;                /* GPE_SCHED_* */
+    float T_0, T_mult, eta_min;   /* cosine warm restarts (refine/...:312-314) */
+    float factor; int32_t patience; float min_lr, threshold;   /* ReduceLROnPlateau (nb c10:L76-78) */
+    /* execution */
+    int32_t path;                 /* GPE_PATH_* */
+    int32_t world_size;           /* data-parallel ranks sharing the replicated boundary batch (>=1) */
+    int32_t history_capacity;     /* steps of scalar history kept on device (0: default 65536) */
+} gpe_config;
+
+/* Per-step scalars (refine/...:364-381 keeps loss every 10 and lambda every 100 epochs). */
+typedef struct gpe_scalars {
+    double loss, pde, bc, norm, sym, orth;
+    double mu;                    /* Rayleigh quotient lambda_pde (refine/...:186-188) */
+    double num, den, sum_r2, integral;
+    double grad_norm, lr;
+    double step;                  /* 1-based optimiser step that produced this record */
+    double reserved[2];
+} gpe_scalars;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+int gpe_abi_version(void);
+size_t gpe_sizeof_config(void);   /* sizeof(gpe_config)  -- lets a foreign-language binding verify its struct layout */
+size_t gpe_sizeof_scalars(void);  /* sizeof(gpe_scalars) */
+/* replaces: GrossPitaevskiiPINN(...).to(device) + torch.optim.Adam(...) + scheduler construction
+ * (refine/harmonic_pinn_simulation.py:295,309-314 ; nb c10:L63,L73-78) */
+int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine** out);
+void gpe_destroy(gpe_engine* e);
+const char* gpe_last_error(const gpe_engine* e); /* e may be NULL: last create() error */
+/* 1 = generic kernels, 2 = fused MFMA kernels (what gpe_create selected) */
+int gpe_active_path(const gpe_engine* e);
+
+/* ---- parameters: model.state_dict() / load_state_dict() (refine/...:299,909,953) --------------- */
+int64_t gpe_param_count(const gpe_engine* e);
+int gpe_set_params(gpe_engine* e, const float* h_flat, size_t n);
+int gpe_get_params(gpe_engine* e, float* h_flat, size_t n);
+int gpe_get_grad(gpe_engine* e, float* h_flat, size_t n);            /* gradient of the last step (after exchange, before clipping) */
+int gpe_get_adam_state(gpe_engine* e, float* h_m, float* h_v, size_t n, int64_t* step);
+int gpe_set_adam_state(gpe_engine* e, const float* h_m, const float* h_v, size_t n, int64_t step);
+int gpe_reset_optimizer(gpe_engine* e, float lr);                    /* new Adam + scheduler state (refine/...:309-314 per gamma) */
+
+/* ---- data binding: X_tensor, boundary_points (refine/...:260-264) ----------------------------------- */
+/* d_x [n_local, dim] row-major fp32; d_V [n_local] or NULL (precomputed_potential, refine/...:146,175-178).
+ * Buffers stay owned by the caller and must outlive their use. */
+int gpe_bind_points(gpe_engine* e, const float* d_x, int64_t n_local, const float* d_V);
+int gpe_bind_boundary(gpe_engine* e, const float* d_xb, int64_t n_b, const float* d_target /* [n_b,out] or NULL = 0 */);
+int gpe_bind_orth(gpe_engine* e, int k, const float* d_psi_k /* [n_local] or NULL to clear */);
+
+/* ---- forward-only entry points ---------------------------------------------------------------- */
+/* model.forward(x) (refine/...:121-125): d_out [n, out] row-major */
+int gpe_forward(gpe_engine* e, const float* d_x, int64_t n, float* d_out);
+/* NN output jets [C][n][out] (replaces the two torch.autograd.grad calls of refine/...:158-172 at the NN output) */
+int gpe_forward_jets(gpe_engine* e, const float* d_x, int64_t n, float* d_jets);
+/* pde_loss (refine/...:146-196 ; nb c6:L81-127) + boundary/normalisation/symmetry terms on the bound data,
+ * no parameter update.  d_psi [n_local,out], d_residual [n_local,out] may be NULL.  Single-rank semantics. */
+int gpe_residual(gpe_engine* e, gpe_scalars* out, float* d_psi, float* d_residual);
+/* plot_wavefunction normalisation (refine/...:463-474 ; nb c12:L30-42): u = base + scale*NN on the grid d_x,
+ * u /= sqrt(sum u^2 * dx), |u| if abs_flag; d_u [n,out], d_density [n] (either may be NULL) */
+int gpe_eval_density(gpe_engine* e, const float* d_x, int64_t n, float dx, int abs_flag, float* d_u, float* d_density);
+
+/* ---- training step: the epoch body refine/...:328-361 ; nb c10:L84-103 ------------------------------ */
+/* phase 1: forward jets + local sums  -> exchange buffer "sums" */
+int gpe_step_begin(gpe_engine* e);
+/* phase 2: residual, seeds, reverse pass -> exchange buffer "grad" (flat gradient + tail scalars) */
+int gpe_step_backward(gpe_engine* e);
+/* phase 3: clip_grad_norm_, Adam, scheduler.step(loss), history record */
+int gpe_step_update(gpe_engine* e);
+/* device buffers to all-reduce(sum) between the phases when world_size > 1 */
+int gpe_exchange_sums(gpe_engine* e, void** d_ptr /* double* */, int64_t* count);
+int gpe_exchange_grad(gpe_engine* e, void** d_ptr /* float*  */, int64_t* count);
+/* Optional: make the engine use CALLER-owned device memory for the two exchange buffers, so that they can be
+ * handed to a collective library as that library's own tensor type.  d_dbl: >= gpe_exchange_dbl_count() doubles
+ * (the first `count` of gpe_exchange_sums() are the all-reduced part), d_grad: >= P + 4 floats. */
+int64_t gpe_exchange_dbl_count(void);
+int gpe_use_external_exchange(gpe_engine* e, void* d_dbl, int64_t n_dbl, void* d_grad, int64_t n_grad);
+/* all three phases + synchronise + scalars (single rank) */
+int gpe_step(gpe_engine* e, gpe_scalars* out);
+/* n steps enqueued back to back, no host synchronisation (single rank) */
+int gpe_run(gpe_engine* e, int64_t n_steps);
+/* synchronise and read the scalars of the most recent step / of steps [first, first+count) (1-based) */
+int gpe_read_scalars(gpe_engine* e, gpe_scalars* out);
+int gpe_read_history(gpe_engine* e, int64_t first_step, int64_t count, gpe_scalars* out);
+int gpe_synchronize(gpe_engine* e);
+
+/* ---- continuation knobs: the gamma / perturbation loop of refine/...:289-340 -------------------------- */
+int gpe_set_gamma(gpe_engine* e, float gamma);
+int gpe_set_power(gpe_engine* e, int p);
+int gpe_set_lr(gpe_engine* e, float lr);
+int gpe_set_perturb_scale(gpe_engine* e, float s);
+int gpe_set_n_global(gpe_engine* e, int64_t n_global);
+
+/* bytes of HBM traffic one step is designed to move (B_mat-style accounting, for bench.py) and FLOPs */
+int gpe_step_cost(const gpe_engine* e, double* flops_per_point, double* hbm_bytes_per_point);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPE_HIP_H */
