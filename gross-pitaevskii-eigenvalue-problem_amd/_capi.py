@@ -92,6 +92,8 @@ SYMBOLS = {
     "gpe_set_lr": (_int, [_vp, _f]),
     "gpe_set_perturb_scale": (_int, [_vp, _f]),
     "gpe_set_n_global": (_int, [_vp, _i64]),
+    "gpe_profile_enable": (_int, [_vp, _int]),
+    "gpe_profile_read": (_int, [_vp, _P(C.c_double)]),
     "gpe_step_cost": (_int, [_vp, _P(C.c_double), _P(C.c_double)]),
 }
 

@@ -179,6 +179,10 @@ struct gpe_engine {
     int nslab = 0;
     bool packed_dirty = true;
     bool ext_exchange = false;
+    bool prof = false;
+    std::vector<hipEvent_t> ev_pool;      // pairs: [2i] start, [2i+1] stop
+    std::vector<int> ev_kind;             // 0 forward, 1 reverse
+    size_t ev_used = 0;
     const float** orth_dev = nullptr;
     const float* orth_host[GPE_MAX_ORTH] = {nullptr, nullptr, nullptr, nullptr};
     Batch main, bc, sym, aux;
@@ -292,14 +296,32 @@ static int ensure_packed(gpe_engine* e) {
     return GPE_OK;
 }
 
+static void prof_mark(gpe_engine* e, int kind, bool start) {
+    if (!e->prof) return;
+    if (start) {
+        if (2 * e->ev_used + 1 >= e->ev_pool.size()) {
+            hipEvent_t a, b2;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b2) != hipSuccess) return;
+            e->ev_pool.push_back(a); e->ev_pool.push_back(b2); e->ev_kind.push_back(kind);
+        } else e->ev_kind[e->ev_used] = kind;
+        e->ev_used++;
+    }
+    if (e->ev_used == 0) return;
+    size_t idx = e->ev_used - 1;
+    (void)hipEventRecord(e->ev_pool[2 * idx + (start ? 0 : 1)], e->stream);
+}
+
 static int mlp_forward(gpe_engine* e, Batch& b, bool store) {
     if (b.n <= 0) return GPE_OK;
+    const bool mark = e->prof && (&b == &e->main);
     if (e->path == GPE_PATH_FUSED) {
         int rc = ensure_packed(e);
         if (rc) return rc;
         unsigned grid = fused_grid(e, b.n);
+        if (mark) prof_mark(e, 0, true);
         if (e->H == 64) { DISPATCH_C(b.C, launch_f_forward<64, CC>(e, b, grid, store ? 1 : 0)); }
         else            { DISPATCH_C(b.C, launch_f_forward<32, CC>(e, b, grid, store ? 1 : 0)); }
+        if (mark) prof_mark(e, 0, false);
     } else {
         const NetDesc& nd = e->nd;
         for (int lin = 0; lin < nd.n_lin; ++lin) {
@@ -320,8 +342,11 @@ static int mlp_backward(gpe_engine* e, Batch& b) {
     if (e->path == GPE_PATH_FUSED) {
         unsigned grid = fused_grid(e, b.n);
         size_t lds = fused_bwd_lds(e);
+        const bool mark = e->prof && (&b == &e->main);
+        if (mark) prof_mark(e, 1, true);
         if (e->H == 64) { DISPATCH_C(b.C, launch_f_backward<64, CC>(e, b, grid, lds)); }
         else            { DISPATCH_C(b.C, launch_f_backward<32, CC>(e, b, grid, lds)); }
+        if (mark) prof_mark(e, 1, false);
         HIPCHK(e, hipGetLastError());
         hipLaunchKernelGGL(k_grad_reduce, dim3(cdiv(e->P, 256)), dim3(256), 0, e->stream, e->gslab, (int)grid, e->Ppad,
                            e->P, e->grad);
@@ -502,6 +527,7 @@ void gpe_destroy(gpe_engine* e) {
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
     free_batch(e->main); free_batch(e->bc); free_batch(e->sym); free_batch(e->aux);
+    for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
     if (e->ext_exchange) { e->grad = nullptr; e->dbl = nullptr; }
     void* ps[] = {e->theta, e->am, e->av, e->grad, e->dbl, e->od, e->hist, e->last, (void*)e->orth_dev, e->Wpk, e->WpkT, e->gslab};
     for (void* p : ps) if (p) (void)hipFree(p);
@@ -826,6 +852,27 @@ int gpe_set_lr(gpe_engine* e, float lr) {
     h.lr = lr; h.lr0 = lr;
     HIPCHK(e, hipMemcpyAsync(e->od, &h, sizeof h, hipMemcpyHostToDevice, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
+    return GPE_OK;
+}
+
+int gpe_profile_enable(gpe_engine* e, int on) {
+    if (!e) return GPE_ERR_INVALID;
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    e->prof = on != 0;
+    e->ev_used = 0;
+    return GPE_OK;
+}
+int gpe_profile_read(gpe_engine* e, double out[4]) {
+    if (!e || !out) return GPE_ERR_INVALID;
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    out[0] = out[1] = out[2] = out[3] = 0.0;
+    for (size_t i = 0; i < e->ev_used; ++i) {
+        float ms = 0.f;
+        HIPCHK(e, hipEventElapsedTime(&ms, e->ev_pool[2 * i], e->ev_pool[2 * i + 1]));
+        out[e->ev_kind[i] ? 2 : 0] += ms;
+        out[e->ev_kind[i] ? 3 : 1] += 1.0;
+    }
+    e->ev_used = 0;
     return GPE_OK;
 }
 

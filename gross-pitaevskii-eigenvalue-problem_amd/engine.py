@@ -336,6 +336,15 @@ class Engine:
         self.cfg.n_global = int(n)
         self._chk(self.lib.gpe_set_n_global(self._h, int(n)))
 
+    def profile_enable(self, on: bool = True):
+        self._chk(self.lib.gpe_profile_enable(self._h, int(on)))
+
+    def profile_read(self):
+        """-> dict(fwd_ms, fwd_launches, bwd_ms, bwd_launches) measured with HIP events on the engine stream."""
+        out = (C.c_double * 4)()
+        self._chk(self.lib.gpe_profile_read(self._h, out))
+        return dict(fwd_ms=out[0], fwd_launches=int(out[1]), bwd_ms=out[2], bwd_launches=int(out[3]))
+
     def step_cost(self):
         f, b = C.c_double(), C.c_double()
         self._chk(self.lib.gpe_step_cost(self._h, C.byref(f), C.byref(b)))

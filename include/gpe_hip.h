@@ -170,6 +170,13 @@ int gpe_set_lr(gpe_engine* e, float lr);
 int gpe_set_perturb_scale(gpe_engine* e, float s);
 int gpe_set_n_global(gpe_engine* e, int64_t n_global);
 
+/* Per-kernel timing with HIP events on the engine's stream (for bench.py's roofline object).  While enabled, every
+ * launch of the two dominant kernels on the collocation batch (jet forward, jet reverse) is bracketed by events.
+ * gpe_profile_read synchronises and returns out[0]=forward ms total, out[1]=forward launches, out[2]=reverse ms total,
+ * out[3]=reverse launches (since the last enable), then clears the counters. */
+int gpe_profile_enable(gpe_engine* e, int on);
+int gpe_profile_read(gpe_engine* e, double out[4]);
+
 /* bytes of HBM traffic one step is designed to move (B_mat-style accounting, for bench.py) and FLOPs */
 int gpe_step_cost(const gpe_engine* e, double* flops_per_point, double* hbm_bytes_per_point);
 
