@@ -292,13 +292,9 @@ class Engine:
         return self._xgrad
 
     def step_distributed(self, group=None, sync: bool = False):
-        """One data-parallel step: every rank holds a shard of the collocation points."""
-        import torch.distributed as dist
-        self.step_begin()
-        dist.all_reduce(self._sums_view, op=dist.ReduceOp.SUM, group=group)
-        self.step_backward()
-        dist.all_reduce(self._xgrad, op=dist.ReduceOp.SUM, group=group)
-        self.step_update()
+        """One data-parallel step: every rank holds a shard of the collocation points (dp.py)."""
+        from .dp import distributed_step
+        distributed_step(self, group)
         if sync:
             return self.read_scalars()
         return None

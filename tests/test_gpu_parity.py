@@ -1,0 +1,343 @@
+"""Parity tests proper: the HIP engine (through the C ABI) against the CPU oracle and against the golden vectors
+produced by the imported reference.  Run on the GPU box:  python -m pytest tests -m gpu -x -q
+
+Tolerances (fp32 kernels vs fp64 oracle unless noted):
+  NN output jets            rel 1e-5 of the channel maximum
+  mu (Rayleigh quotient)    rel 2e-5          loss pieces   rel 1e-4 (differences of O(1) terms)
+  gradient                  rel 5e-5 of max|g| vs the oracle ; rel 5e-4 vs the reference's fp32 autograd gradient
+  trajectories              as in tests/test_oracle_golden.py (fp32 chaos grows with the step count)
+"""
+import numpy as np
+import pytest
+import torch
+
+import gpe_pinn
+from gpe_pinn import GPEConfig, Engine
+from oracle import gpe_oracle as go
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+PATHS = {"generic": gpe_pinn.PATH_GENERIC, "fused": gpe_pinn.PATH_FUSED}
+
+
+def cfg_from_problem(pb: go.Problem, **kw) -> GPEConfig:
+    d = dict(layers=list(pb.layers), activation=pb.activation, complex_psi=pb.complex_psi, kinetic_coeff=pb.kinetic_coeff,
+             potential=pb.potential, pot_scale=pb.pot_scale, omega=tuple(pb.omega), pot_a=pb.pot_a, pot_v0=pb.pot_v0,
+             pot_k=pb.pot_k, omega_rot=pb.omega_rot, gamma=pb.gamma, p=pb.p, abs_power=pb.abs_power,
+             base_mode=pb.base_mode, base_deriv=pb.base_deriv, perturb_scale=pb.perturb_scale,
+             bc_nn_scale=pb.bc_nn_scale, w_pde=pb.w_pde, w_bc=pb.w_bc, w_norm=pb.w_norm, w_sym=pb.w_sym,
+             w_orth=pb.w_orth, sym_sign=pb.sym_sign, dx=pb.dx, n_global=pb.n_global)
+    d.update(kw)
+    return GPEConfig(**d)
+
+
+def make_engine(pb, flat, x, x_bc=None, **kw):
+    cfg = cfg_from_problem(pb, **kw)
+    if x_bc is None:
+        cfg.w_bc = 0.0
+    eng = Engine(cfg)
+    eng.set_params(flat)
+    eng.bind_points(torch.as_tensor(np.asarray(x, np.float32), device="cuda"))
+    if x_bc is not None:
+        eng.bind_boundary(torch.as_tensor(np.asarray(x_bc, np.float32), device="cuda"))
+    return eng
+
+
+CASES = {
+    # name: (Problem kwargs, N, fused-capable)
+    "1d_64x3_refine": (dict(layers=[1, 64, 64, 64, 1], activation=1, kinetic_coeff=1.0, pot_scale=1.0, gamma=5.0, p=3,
+                            base_mode=0, perturb_scale=0.05, dx=12 / 499), 500, True),
+    "1d_32x4_nb_sym": (dict(layers=[1, 32, 32, 32, 32, 1], gamma=1.0, p=3, base_mode=0, base_deriv=1, w_sym=5.0,
+                            dx=12 / 299), 300, True),
+    "1d_64x4_m3_p4_odd": (dict(layers=[1, 64, 64, 64, 64, 1], activation=1, gamma=2.0, p=4, base_mode=3, perturb_scale=0.1,
+                               w_sym=5.0, sym_sign=-1.0, dx=12 / 1000), 1001, True),
+    "1d_abs_power_p2": (dict(layers=[1, 32, 32, 1], gamma=3.0, p=2, abs_power=True, base_mode=1, dx=0.03), 333, True),
+    "1d_gaussian_pot": (dict(layers=[1, 32, 32, 32, 1], potential=go.POT_GAUSSIAN, pot_a=0.5, gamma=1.0, dx=0.03), 200, True),
+    "1d_periodic_pot": (dict(layers=[1, 32, 32, 32, 1], potential=go.POT_PERIODIC, gamma=1.0, dx=0.03), 200, True),
+    "2d_64x4_g500": (dict(layers=[2, 64, 64, 64, 64, 1], gamma=500.0, dx=36 / 777), 777, True),
+    "2d_32x3": (dict(layers=[2, 32, 32, 32, 1], gamma=10.0, dx=0.05), 100, True),
+    "3d_64x3_aniso": (dict(layers=[3, 64, 64, 64, 1], gamma=20.0, dx=0.01, omega=(1.0, 1.4, 2.0)), 130, True),
+    "2d_64x3_complex_rot": (dict(layers=[2, 64, 64, 64, 2], complex_psi=True, gamma=30.0, dx=0.02, omega_rot=0.8), 200, True),
+    "2d_N1": (dict(layers=[2, 64, 64, 1], gamma=3.0, dx=0.1), 1, True),
+    "2d_N17_ragged": (dict(layers=[2, 64, 64, 1], gamma=3.0, dx=0.1), 17, True),
+    "2d_128x3_cfg3like": (dict(layers=[2, 128, 128, 128, 1], gamma=100.0, dx=0.01), 300, False),
+    "2d_128x6_complex_cfg4like": (dict(layers=[2, 128, 128, 2], complex_psi=True, gamma=50.0, omega_rot=0.8, dx=0.01), 150, False),
+    "3d_256x2_cfg5like": (dict(layers=[3, 256, 256, 1], gamma=100.0, dx=0.01, omega=(1.0, 1.4, 2.0)), 64, False),
+    "2d_100x2_odd_width": (dict(layers=[2, 100, 100, 1], gamma=1.0, dx=0.01), 77, False),
+    "1d_single_hidden": (dict(layers=[1, 64, 1], gamma=1.0, dx=0.01, base_mode=1), 50, False),
+}
+
+
+def _inputs(kw, N, seed=0, scale=0.3):
+    rng = np.random.default_rng(seed)
+    layers = kw["layers"]
+    d = layers[0]
+    x = np.linspace(-6, 6, N).reshape(-1, 1) if d == 1 else rng.uniform(-3, 3, (N, d))
+    x = x.astype(np.float32)
+    flat = (rng.normal(0, 1, go.param_count(layers)) * scale).astype(np.float32)
+    x_bc = (np.array([[-6.0], [6.0]]) if d == 1 else rng.uniform(-3, 3, (5, d))).astype(np.float32)
+    return x, flat, x_bc
+
+
+def _case_params():
+    out = []
+    for name, (kw, N, fused_ok) in CASES.items():
+        out.append(pytest.param(name, "generic", id=f"{name}-generic"))
+        if fused_ok:
+            out.append(pytest.param(name, "fused", id=f"{name}-fused"))
+    return out
+
+
+@pytest.mark.parametrize("name,path", _case_params())
+def test_step_matches_oracle(name, path):
+    kw, N, _ = CASES[name]
+    scale = 0.15 if max(kw["layers"][1:-1]) > 64 else 0.3
+    x, flat, x_bc = _inputs(kw, N, scale=scale)
+    pb = go.Problem(**kw)
+    osc, ograd, ores = go.full_loss_and_grad(pb, flat.astype(np.float64), x.astype(np.float64), x_bc.astype(np.float64))
+    ojets, _ = go.mlp_forward(go.unflatten(flat.astype(np.float64), pb.layers), x.astype(np.float64), pb.activation)
+    eng = make_engine(pb, flat, x, x_bc, path=PATHS[path])
+    assert eng.active_path == PATHS[path]
+    jets = eng.forward_jets(torch.as_tensor(x, device="cuda")).cpu().numpy()
+    for c in range(jets.shape[0]):
+        assert H.rel_err(jets[c], ojets[c]) < 1e-5, f"jet channel {c}"
+    val = eng.forward(torch.as_tensor(x, device="cuda")).cpu().numpy()
+    assert H.rel_err(val, ojets[0]) < 1e-5
+    rs, psi, res = eng.residual()
+    assert H.rel_err(psi.cpu().numpy(), ores["psi"]) < 5e-6
+    assert H.rel_err(res.cpu().numpy(), ores["residual"]) < 2e-5
+    sc = eng.step()
+    for k, tol in (("mu", 2e-5), ("loss", 1e-4), ("pde", 1e-4), ("bc", 1e-4), ("norm", 2e-4), ("sym", 1e-4)):
+        assert abs(sc[k] - osc[k]) <= tol * max(abs(osc[k]), 1e-6), (k, sc[k], osc[k])
+    assert abs(rs["loss"] - osc["loss"]) <= 1e-4 * abs(osc["loss"])
+    grad = eng.get_grad()
+    assert H.rel_err(grad, ograd) < 5e-5
+    assert abs(sc["grad_norm"] - np.linalg.norm(ograd)) < 1e-4 * np.linalg.norm(ograd)
+    # Adam + clip on the device vs the oracle's optimiser (first step moves every weight by ~lr)
+    new, _, _ = go.optimizer_step(go.OptState(lr0=1e-3), flat, ograd, osc["loss"])
+    d = np.abs(eng.get_params() - new)
+    assert np.quantile(d, 0.99) < 2e-5 and d.max() < 2.1e-3
+    eng.close()
+
+
+def test_fused_and_generic_agree_full_size():
+    """BASELINE north-star size (1 048 576 points, [2,64x4,1]): the two kernel sets are independent implementations;
+    their sums and gradients must agree at full size (size-independent cross-check, no oracle needed)."""
+    N = 1 << 20
+    kw = dict(layers=[2, 64, 64, 64, 64, 1], gamma=500.0, dx=(16.0 / 1023) ** 2)
+    rng = np.random.default_rng(1)
+    xs = np.linspace(-8, 8, 1024, dtype=np.float32)
+    X, Y = np.meshgrid(xs, xs, indexing="ij")
+    x = np.stack([X.ravel(), Y.ravel()], 1)
+    flat = (rng.normal(0, 1, go.param_count(kw["layers"])) * 0.2).astype(np.float32)
+    pb = go.Problem(**kw)
+    outs = {}
+    for path in ("generic", "fused"):
+        eng = make_engine(pb, flat, x, None, path=PATHS[path])
+        sc = eng.step()
+        outs[path] = (sc, eng.get_grad())
+        eng.close()
+    (a, ga), (b, gb) = outs["generic"], outs["fused"]
+    assert abs(a["mu"] - b["mu"]) < 1e-5 * abs(a["mu"])
+    assert abs(a["loss"] - b["loss"]) < 1e-4 * abs(a["loss"])
+    assert H.rel_err(gb, ga) < 2e-4
+
+
+def test_shard_additivity_two_engines_one_gpu():
+    """world_size = 2 emulated on one GPU: two engines own the two halves of the points, the exchange buffers are
+    summed by hand (what the RCCL all-reduce does), and the result must equal the single-engine step."""
+    kw = dict(layers=[2, 64, 64, 64, 1], gamma=50.0, dx=0.01)
+    N = 4099
+    x, flat, x_bc = _inputs(kw, N)
+    pb = go.Problem(**kw, n_global=N)
+    full = make_engine(pb, flat, x, x_bc)
+    ref = full.step()
+    gref = full.get_grad()
+    pref = full.get_params()
+    lo = N // 2
+    engs = [make_engine(pb, flat, x[:lo], x_bc, world_size=2), make_engine(pb, flat, x[lo:], x_bc, world_size=2)]
+    for e in engs:
+        e.step_begin()
+    tot = engs[0].exchange_sums + engs[1].exchange_sums
+    for e in engs:
+        e.exchange_sums.copy_(tot)
+        e.step_backward()
+    gt = engs[0].exchange_grad + engs[1].exchange_grad
+    for e in engs:
+        e.exchange_grad.copy_(gt)
+        e.step_update()
+    scs = [e.read_scalars() for e in engs]
+    for sc in scs:
+        assert abs(sc["mu"] - ref["mu"]) < 1e-6 * abs(ref["mu"])
+        assert abs(sc["loss"] - ref["loss"]) < 1e-5 * abs(ref["loss"])
+        assert abs(sc["bc"] - ref["bc"]) < 1e-6 * abs(ref["bc"])
+    assert H.rel_err(engs[0].get_grad(), gref) < 1e-5
+    np.testing.assert_array_equal(engs[0].get_params(), engs[1].get_params())     # replicas stay bit-identical
+    assert np.abs(engs[0].get_params() - pref).max() < 2e-5
+
+
+@pytest.mark.parametrize("name", H.refine_names())
+@pytest.mark.parametrize("path", ["generic", "fused"])
+def test_golden_refine_oplevel(name, path):
+    """Engine vs numbers produced by the reference's own refine/ classes (tests/golden/make_golden.py)."""
+    fx = H.load_fx(name)
+    pb = H.problem_from_refine(fx)
+    eng = make_engine(pb, fx["flat0"], fx["x"], H.bc_points(fx), path=PATHS[path])
+    xt = torch.as_tensor(fx["x"], device="cuda")
+    assert H.rel_err(eng.forward(xt).cpu().numpy(), fx["nn_out"]) < 1e-5
+    rs, psi, res = eng.residual()
+    assert H.rel_err(psi.cpu().numpy(), fx["u"]) < 2e-6
+    assert abs(rs["mu"] - float(fx["lam"])) < 2e-5 * max(1.0, abs(float(fx["lam"])))
+    assert H.rel_err(res.cpu().numpy(), fx["residual"]) < 1e-4
+    sc = eng.step()
+    assert abs(sc["pde"] - float(fx["pde_loss"])) < 2e-4 * max(1e-3, float(fx["pde_loss"]))
+    assert abs(sc["bc"] - float(fx["bc_loss"])) < 1e-5 * max(1e-6, float(fx["bc_loss"])) + 1e-12
+    assert abs(sc["norm"] - float(fx["norm_loss"])) < 1e-4 * max(1e-3, float(fx["norm_loss"]))
+    assert abs(sc["loss"] - float(fx["total"])) < 1e-4 * max(1e-3, float(fx["total"]))
+    assert H.rel_err(eng.get_grad(), fx["grad0"]) < 5e-4
+    eng.close()
+
+
+@pytest.mark.parametrize("name", H.nb_names())
+@pytest.mark.parametrize("path", ["generic", "fused"])
+def test_golden_notebook_oplevel(name, path):
+    fx = H.load_fx(name)
+    pb = H.problem_from_nb(fx)
+    eng = make_engine(pb, fx["flat0"], fx["x"], H.bc_points(fx), path=PATHS[path])
+    rs, psi, res = eng.residual()
+    assert H.rel_err(psi.cpu().numpy(), fx["u"]) < 2e-6
+    assert abs(rs["mu"] - float(fx["lam"])) < 5e-5 * max(1.0, abs(float(fx["lam"])))
+    assert H.rel_err(res.cpu().numpy(), fx["residual"]) < 2e-4
+    sc = eng.step()
+    assert abs(sc["sym"] - float(fx["sym_loss"])) < 1e-4 * max(1e-6, float(fx["sym_loss"]))
+    assert abs(sc["loss"] - float(fx["total"])) < 2e-4 * float(fx["total"])
+    assert H.rel_err(eng.get_grad(), fx["grad0"]) < 5e-4
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["fx_refine_m0_g0_64x3.npz", "fx_refine_m0_g50_64x3.npz", "fx_refine_m2_g10_32x4.npz"])
+def test_golden_refine_trace(name):
+    """(loss, mu, lr) over 25 epochs of the reference loop (Adam, clip 1.0, cosine scheduler stepped with the loss)."""
+    fx = H.load_fx(name)
+    pb = H.problem_from_refine(fx)
+    eng = make_engine(pb, fx["flat0"], fx["x"], H.bc_points(fx), lr=1e-3, sched=gpe_pinn.SCHED_COSINE_LOSS)
+    n = 25
+    eng.run(n)                                          # enqueued back to back, scheduler on the device
+    hist = eng.read_history(1, n)
+    loss = np.array([h["loss"] for h in hist]); mu = np.array([h["mu"] for h in hist])
+    lr = np.array([h["lr"] for h in hist]); gn = np.array([h["grad_norm"] for h in hist])
+    assert [int(h["step"]) for h in hist] == list(range(1, n + 1))
+    np.testing.assert_allclose(lr, fx["trace_lr"][:n], rtol=2e-3, atol=1e-9)
+    np.testing.assert_allclose(loss[:10], fx["trace_loss"][:10], rtol=2e-3)
+    np.testing.assert_allclose(mu[:10], fx["trace_mu"][:10], rtol=5e-4)
+    np.testing.assert_allclose(gn[:5], fx["trace_gnorm"][:5], rtol=2e-3)
+    np.testing.assert_allclose(loss, fx["trace_loss"][:n], rtol=5e-2)
+    np.testing.assert_allclose(mu, fx["trace_mu"][:n], rtol=5e-3)
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["fx_nb_m0_g1_p3_32x4.npz", "fx_nb_m0_g1_p2_64x3.npz"])
+def test_golden_notebook_trace(name):
+    fx = H.load_fx(name)
+    pb = H.problem_from_nb(fx)
+    eng = make_engine(pb, fx["flat0"], fx["x"], H.bc_points(fx), lr=1e-3, sched=gpe_pinn.SCHED_PLATEAU)
+    n = 20
+    trace = [eng.step() for _ in range(n)]
+    loss = np.array([t["loss"] for t in trace]); mu = np.array([t["mu"] for t in trace])
+    np.testing.assert_allclose(loss[:8], fx["trace_loss"][:8], rtol=3e-3)
+    np.testing.assert_allclose(mu[:8], fx["trace_mu"][:8], rtol=2e-3)
+    np.testing.assert_allclose(loss, fx["trace_loss"][:n], rtol=8e-2)
+    eng.close()
+
+
+@pytest.mark.parametrize("name", H.refine_names())
+def test_eval_density_refine(name):
+    fx = H.load_fx(name)
+    pb = H.problem_from_refine(fx)
+    eng = make_engine(pb, fx["flat_final"], fx["x"], None)
+    xt = fx["eval_x"]
+    u, dens = eng.eval_density(torch.as_tensor(xt, device="cuda"), float(xt[1, 0] - xt[0, 0]),
+                               abs_flag=(int(fx["mode"]) == 0))
+    assert H.rel_err(u.cpu().numpy()[:, 0], fx["eval_u"]) < 5e-5
+    eng.close()
+
+
+def test_known_answer_zero_perturbation():
+    """with zero perturbation u = phi_n exactly, so lambda = 2n+1 (refine convention) and pde_loss ~ 0,
+    at BASELINE cfg2's full size (65 536 points)."""
+    N = 65536
+    x = np.linspace(-10, 10, N, dtype=np.float64).reshape(-1, 1)
+    for mode in (0, 1, 4):
+        pb = go.Problem(layers=[1, 64, 64, 64, 64, 1], activation=1, kinetic_coeff=1.0, pot_scale=1.0, gamma=0.0,
+                        base_mode=mode, perturb_scale=0.0, dx=20.0 / (N - 1), w_bc=0.0)
+        flat = np.random.default_rng(mode).normal(0, 0.2, go.param_count(pb.layers))
+        eng = make_engine(pb, flat, x, None)
+        sc, _, _ = eng.residual(want_fields=False)
+        assert abs(sc["mu"] - (2 * mode + 1)) < 2e-5 * (2 * mode + 1)
+        assert sc["pde"] < 1e-8
+        assert abs(sc["integral"] - 1.0) < 1e-5
+        eng.close()
+
+
+def test_history_and_run_equivalence():
+    kw = dict(layers=[1, 32, 32, 1], gamma=1.0, base_mode=0, dx=0.05)
+    x, flat, x_bc = _inputs(kw, 256)
+    pb = go.Problem(**kw)
+    a = make_engine(pb, flat, x, x_bc)
+    b = make_engine(pb, flat, x, x_bc)
+    ta = [a.step() for _ in range(7)]
+    b.run(7)
+    hb = b.read_history(1, 7)
+    for s, h in zip(ta, hb):
+        assert abs(s["loss"] - h["loss"]) <= 1e-6 * abs(s["loss"]) and s["step"] == h["step"]
+    assert np.abs(a.get_params() - b.get_params()).max() < 1e-6
+    m, v, step = a.get_adam_state()
+    assert step == 7 and np.isfinite(m).all() and (v >= 0).all()
+
+
+def test_error_behaviour():
+    with pytest.raises(ValueError):                                   # reference: ValueError("Unknown potential type")
+        Engine(GPEConfig(layers=[1, 32, 32, 1], potential=17))
+    with pytest.raises(ValueError):
+        Engine(GPEConfig(layers=[4, 32, 32, 1]))
+    with pytest.raises(ValueError):
+        Engine(GPEConfig(layers=[2, 128, 128, 1], path=gpe_pinn.PATH_FUSED))
+    eng = Engine(GPEConfig(layers=[1, 32, 32, 1]))
+    with pytest.raises(gpe_pinn.GPEError) as ei:
+        eng.step()
+    assert ei.value.code == gpe_pinn.capi.GPE_ERR_STATE
+    with pytest.raises(gpe_pinn.GPEError):
+        eng.set_params(np.zeros(5, np.float32))
+    # non-finite loss: parameters must not move, status NONFINITE
+    eng.set_params(np.full(eng.n_params, np.nan, np.float32))
+    eng.bind_points(torch.zeros((16, 1), device="cuda"))
+    before = eng.get_params()
+    with pytest.raises(gpe_pinn.GPEError) as ei:
+        eng.step()
+    assert ei.value.code == gpe_pinn.capi.GPE_ERR_NONFINITE
+    after = eng.get_params()
+    assert np.array_equal(np.isnan(before), np.isnan(after))
+
+
+def test_tanh_accuracy_through_forward():
+    """The device tanh (gpe_common.h) against numpy over the whole useful range, via a 1-hidden-unit-wide network."""
+    layers = [1, 32, 32, 1]
+    P = go.param_count(layers)
+    flat = np.zeros(P, np.float32)
+    params = go.unflatten(flat, layers)
+    # first layer: identity-ish scaling so that z spans [-12, 12]
+    W0 = np.zeros((32, 1), np.float32); W0[:, 0] = np.linspace(0.01, 1.0, 32)
+    params[0] = (W0, np.zeros(32, np.float32))
+    W1 = np.eye(32, dtype=np.float32) * 3.0
+    params[1] = (W1, np.zeros(32, np.float32))
+    params[2] = (np.ones((1, 32), np.float32), np.zeros(1, np.float32))
+    flat = go.flatten(params).astype(np.float32)
+    x = np.linspace(-12, 12, 4097, dtype=np.float32).reshape(-1, 1)
+    for path in ("generic", "fused"):
+        eng = Engine(GPEConfig(layers=layers, path=PATHS[path]))
+        eng.set_params(flat)
+        got = eng.forward(torch.as_tensor(x, device="cuda")).cpu().numpy()
+        ref, _ = go.mlp_forward(go.unflatten(flat.astype(np.float64), layers), x.astype(np.float64), 0, value_only=True)
+        assert np.abs(got - ref[0]).max() < 2e-5          # sum of 32 tanh values, each good to ~3e-7
+        eng.close()
