@@ -37,6 +37,7 @@ class gpe_config(C.Structure):
         ("sched", C.c_int32), ("T_0", C.c_float), ("T_mult", C.c_float), ("eta_min", C.c_float),
         ("factor", C.c_float), ("patience", C.c_int32), ("min_lr", C.c_float), ("threshold", C.c_float),
         ("path", C.c_int32), ("world_size", C.c_int32), ("history_capacity", C.c_int32),
+        ("stop_tol", C.c_float), ("stop_patience", C.c_int32),
     ]
 
 
@@ -87,6 +88,7 @@ SYMBOLS = {
     "gpe_read_scalars": (_int, [_vp, _P(gpe_scalars)]),
     "gpe_read_history": (_int, [_vp, _i64, _i64, _P(gpe_scalars)]),
     "gpe_synchronize": (_int, [_vp]),
+    "gpe_stop_state": (_int, [_vp, _P(_int), _P(_i64)]),
     "gpe_set_gamma": (_int, [_vp, _f]),
     "gpe_set_power": (_int, [_vp, _int]),
     "gpe_set_lr": (_int, [_vp, _f]),

@@ -51,6 +51,10 @@ struct OptDev {
     int num_bad;
     int nonfinite;        // sticky flag: a non-finite loss/grad was seen, updates were skipped
     long long step;       // optimiser steps taken
+    int stopped;          // early stop fired (refine/harmonic_pinn_simulation.py:389-400)
+    int es_count;         // steps since the best loss
+    double es_best;
+    long long stop_step;
 };
 
 struct OptCfg {
@@ -58,6 +62,7 @@ struct OptCfg {
     int sched;
     float T_0, T_mult, eta_min;
     float factor; int patience; float min_lr, threshold;
+    float stop_tol; int stop_patience;
 };
 
 // ------------------------------------------------------------------------------------------------

@@ -79,7 +79,8 @@ __global__ __launch_bounds__(1024) void k_update(int P, float* __restrict__ thet
         for (int j = 0; j < ph.n_orth; ++j) { double oj = sums[S_ORTH0 + j] * ph.dx; orth += oj * oj; }
         double loss = ph.w_pde * pde + ph.w_bc * bc + ph.w_norm * nrm + ph.w_sym * sym + ph.w_orth * orth;
         int skip = !(isfinite(loss) && isfinite(gn));
-        long long step = od->step + (do_update && !skip ? 1 : 0);
+        const int frozen = do_update && od->stopped;
+        long long step = od->step + (do_update && !skip && !frozen ? 1 : 0);
         double lr = od->lr;
         float coef = 1.0f;
         if (oc.clip_norm > 0.f) coef = (float)fmin(1.0, (double)oc.clip_norm / (gn + 1e-6));
@@ -88,16 +89,20 @@ __global__ __launch_bounds__(1024) void k_update(int P, float* __restrict__ thet
         s_coef = coef;
         s_ss = (float)(lr / bc1);
         s_b2s = (float)sqrt(bc2);
-        s_skip = skip || !do_update;
+        s_skip = skip || !do_update || frozen;
         gpe_scalars r;
         r.loss = loss; r.pde = pde; r.bc = bc; r.norm = nrm; r.sym = sym; r.orth = orth; r.mu = lam;
         r.num = num; r.den = den; r.sum_r2 = sr2; r.integral = I; r.grad_norm = gn; r.lr = lr;
         r.step = (double)step; r.reserved[0] = skip ? 1.0 : 0.0; r.reserved[1] = 0.0;
-        *last = r;
-        if (do_update) {
+        if (!frozen) *last = r;
+        if (do_update && !frozen) {
             if (!skip) {
                 hist[(step - 1) % cap] = r;
                 od->step = step;
+                // early stopping bookkeeping (refine/...:366-372, 389-400)
+                if (loss < od->es_best) { od->es_best = loss; od->es_count = 0; } else od->es_count += 1;
+                if ((oc.stop_tol > 0.f && loss <= (double)oc.stop_tol) ||
+                    (oc.stop_patience > 0 && od->es_count >= oc.stop_patience)) { od->stopped = 1; od->stop_step = step; }
                 // scheduler.step(total_loss)
                 if (oc.sched == GPE_SCHED_COSINE_LOSS) {           // quirk Q4: the loss value is the epoch
                     double epoch = (double)(float)loss, T_cur, T_i;
@@ -402,12 +407,14 @@ static void fill_phys(gpe_engine* e) {
     o.beta1 = c.beta1; o.beta2 = c.beta2; o.eps = c.eps; o.clip_norm = c.clip_norm; o.sched = c.sched;
     o.T_0 = c.T_0; o.T_mult = c.T_mult; o.eta_min = c.eta_min; o.factor = c.factor; o.patience = c.patience;
     o.min_lr = c.min_lr; o.threshold = c.threshold;
+    o.stop_tol = c.stop_tol; o.stop_patience = c.stop_patience;
 }
 
 static int reset_opt(gpe_engine* e, float lr) {
     OptDev h;
     memset(&h, 0, sizeof h);
     h.lr = lr; h.lr0 = lr; h.best = INFINITY; h.num_bad = 0; h.nonfinite = 0; h.step = 0;
+    h.stopped = 0; h.es_count = 0; h.es_best = INFINITY; h.stop_step = 0;
     HIPCHK(e, hipMemcpyAsync(e->od, &h, sizeof h, hipMemcpyHostToDevice, e->stream));
     HIPCHK(e, hipMemsetAsync(e->am, 0, (size_t)e->P * sizeof(float), e->stream));
     HIPCHK(e, hipMemsetAsync(e->av, 0, (size_t)e->P * sizeof(float), e->stream));
@@ -873,6 +880,16 @@ int gpe_profile_read(gpe_engine* e, double out[4]) {
         out[e->ev_kind[i] ? 3 : 1] += 1.0;
     }
     e->ev_used = 0;
+    return GPE_OK;
+}
+
+int gpe_stop_state(gpe_engine* e, int* stopped, int64_t* stop_step) {
+    if (!e) return GPE_ERR_INVALID;
+    OptDev h;
+    HIPCHK(e, hipMemcpyAsync(&h, e->od, sizeof h, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (stopped) *stopped = h.stopped;
+    if (stop_step) *stop_step = h.stop_step;
     return GPE_OK;
 }
 

@@ -67,6 +67,8 @@ class GPEConfig:
     path: int = capi.PATH_AUTO
     world_size: int = 1
     history_capacity: int = 0
+    stop_tol: float = 0.0
+    stop_patience: int = 0
 
     def to_c(self) -> capi.gpe_config:
         c = capi.gpe_config()
@@ -81,13 +83,14 @@ class GPEConfig:
         for i in range(3):
             c.omega[i] = float(om[i])
         for name in ("activation", "potential", "p", "base_mode", "base_deriv", "sched", "patience", "path",
-                     "world_size", "history_capacity", "n_global"):
+                     "world_size", "history_capacity", "n_global", "stop_patience"):
             setattr(c, name, int(getattr(self, name)))
         c.complex_psi = int(bool(self.complex_psi))
         c.abs_power = int(bool(self.abs_power))
         for name in ("kinetic_coeff", "pot_scale", "pot_a", "pot_v0", "pot_k", "omega_rot", "gamma", "perturb_scale",
                      "bc_nn_scale", "w_pde", "w_bc", "w_norm", "w_sym", "w_orth", "sym_sign", "dx", "lr", "beta1",
-                     "beta2", "eps", "clip_norm", "T_0", "T_mult", "eta_min", "factor", "min_lr", "threshold"):
+                     "beta2", "eps", "clip_norm", "T_0", "T_mult", "eta_min", "factor", "min_lr", "threshold",
+                     "stop_tol"):
             setattr(c, name, float(getattr(self, name)))
         return c
 
@@ -301,6 +304,12 @@ class Engine:
 
     def synchronize(self):
         self._chk(self.lib.gpe_synchronize(self._h))
+
+    def stop_state(self):
+        """(stopped, stop_step): early stopping evaluated on the device (refine/harmonic_pinn_simulation.py:389-400)."""
+        s, st = C.c_int(), C.c_int64()
+        self._chk(self.lib.gpe_stop_state(self._h, C.byref(s), C.byref(st)))
+        return bool(s.value), int(st.value)
 
     def read_scalars(self) -> dict:
         sc = capi.gpe_scalars()

@@ -1,0 +1,489 @@
+"""The reference's Python surface for the hot path, re-hosted on the HIP engine.
+
+Same class / function names, argument meaning and return shapes as
+  refine flavour   : Gross-Pitaevskii/src/final/refine/harmonic_pinn_simulation.py  (class :52-217, train_gpe_model :220-430,
+                     advanced_initialization :636-647, plot_wavefunction's normalisation :459-474)
+  notebook flavour : Gross_Pitaevskii_1D_power_Test.ipynb  (class c6, train_gpe_model c10, advanced_initialization c18,
+                     density c12:L30-42)
+so that a caller of the reference can switch imports:
+
+    from gpe_pinn.surface import refine          # refine.GrossPitaevskiiPINN, refine.train_gpe_model, ...
+    from gpe_pinn.surface import notebook        # notebook.GrossPitaevskiiPINN, notebook.train_gpe_model, ...
+
+Every loss / derivative / optimiser number comes from libgpe_hip.so (C ABI, include/gpe_hip.h).  torch is used for
+device storage, for the SAME host RNG the reference uses in its weight init (so seeded runs start from identical
+weights) and for torch.distributed.  There is no autograd and no CPU compute path here.
+"""
+from __future__ import annotations
+
+import math
+import types
+from collections import OrderedDict
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _capi as capi
+from .engine import Engine, GPEConfig
+
+_POT = {"harmonic": capi.POT_HARMONIC, "gaussian": capi.POT_GAUSSIAN, "periodic": capi.POT_PERIODIC}
+
+
+def _device():
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class _Flavor:
+    def __init__(self, name, activation, kinetic, pot_scale, base_deriv, w_sym, init_kind):
+        self.name, self.activation, self.kinetic, self.pot_scale = name, activation, kinetic, pot_scale
+        self.base_deriv, self.w_sym, self.init_kind = base_deriv, w_sym, init_kind
+
+
+_REFINE = _Flavor("refine", capi.ACT_TANH_PLUS1, 1.0, 1.0, 0, 0.0, "xavier_normal")
+_NOTEBOOK = _Flavor("notebook", capi.ACT_TANH, 0.5, 0.5, 1, 5.0, "xavier_uniform")
+
+
+def _layer_shapes(layers):
+    return [(layers[i + 1], layers[i]) for i in range(len(layers) - 1)]
+
+
+def _state_dict_from_flat(flat: np.ndarray, layers) -> "OrderedDict[str, torch.Tensor]":
+    """keys network.{2k}.weight / .bias as nn.Sequential(Linear, act, Linear, ...) gives them."""
+    sd, o = OrderedDict(), 0
+    for k, (fo, fi) in enumerate(_layer_shapes(layers)):
+        sd[f"network.{2 * k}.weight"] = torch.from_numpy(flat[o:o + fo * fi].reshape(fo, fi).copy()); o += fo * fi
+        sd[f"network.{2 * k}.bias"] = torch.from_numpy(flat[o:o + fo].copy()); o += fo
+    return sd
+
+
+def _flat_from_state_dict(sd, layers) -> np.ndarray:
+    parts = []
+    for k, (fo, fi) in enumerate(_layer_shapes(layers)):
+        W = sd[f"network.{2 * k}.weight"]
+        b = sd[f"network.{2 * k}.bias"]
+        W = W.detach().cpu().numpy() if isinstance(W, torch.Tensor) else np.asarray(W)
+        b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+        if W.shape != (fo, fi) or b.shape != (fo,):
+            raise RuntimeError(f"size mismatch for network.{2 * k}: got {W.shape}/{b.shape}, expected {(fo, fi)}/{(fo,)}")
+        parts += [W.astype(np.float32).ravel(), b.astype(np.float32).ravel()]
+    return np.concatenate(parts)
+
+
+def _default_init(layers) -> np.ndarray:
+    """nn.Linear's default init (kaiming_uniform(a=sqrt 5) + uniform bias), drawn from torch's global CPU RNG in the same
+    order the reference's constructor draws it (refine/...:90)."""
+    parts = []
+    for fo, fi in _layer_shapes(layers):
+        lin = torch.nn.Linear(fi, fo)
+        parts += [lin.weight.detach().numpy().ravel(), lin.bias.detach().numpy().ravel()]
+    return np.concatenate(parts).astype(np.float32)
+
+
+def _advanced_init(layers, mode, kind) -> np.ndarray:
+    """advanced_initialization: refine/...:636-647 (Xavier-normal, gain 1/(1+0.2 mode), bias 0.01 | 0.001 if mode>3);
+    nb c18 (Xavier-uniform, gain 1/(1+0.1 mode), bias 0.01).  Uses torch's CPU RNG exactly as model.apply() does."""
+    parts = []
+    for fo, fi in _layer_shapes(layers):
+        W = torch.empty(fo, fi)
+        if kind == "xavier_normal":
+            torch.nn.init.xavier_normal_(W, gain=1.0 / (1.0 + 0.2 * mode))
+            bias = 0.001 if mode > 3 else 0.01
+        else:
+            torch.nn.init.xavier_uniform_(W, gain=1.0 / (1.0 + 0.1 * mode))
+            bias = 0.01
+        parts += [W.numpy().ravel(), np.full(fo, bias, np.float32)]
+    return np.concatenate(parts).astype(np.float32)
+
+
+class _PINNBase:
+    """Parameter container + per-call loss surface.  The training loop does not go through these methods (it drives
+    Engine.step / Engine.run); they exist so that code written against the reference class keeps working."""
+    _flavor: _Flavor = None
+
+    def __init__(self, layers, hbar=1.0, m=1.0, mode=0, gamma=1.0):
+        self.layers = list(layers)
+        self.hbar, self.m, self.mode, self.gamma = hbar, m, mode, gamma
+        self._flat = _default_init(self.layers)           # nn.Linear default init, as the reference constructor does
+        self._engine: Optional[Engine] = None
+        self._engine_key = None
+        self.perturb_scale = 1.0
+
+    # -- nn.Module-like conveniences ---------------------------------------------------------------
+    def to(self, device=None):
+        return self
+
+    def eval(self):
+        return self
+
+    def train(self, mode=True):
+        return self
+
+    def cpu(self):
+        return self
+
+    def apply(self, fn):
+        """model.apply(lambda m: advanced_initialization(m, mode)): the initialiser is applied to the whole flat vector."""
+        fn(self)
+        return self
+
+    def parameters(self):
+        return [torch.from_numpy(self._flat)]
+
+    def state_dict(self):
+        self._pull()
+        return _state_dict_from_flat(self._flat, self.layers)
+
+    def load_state_dict(self, sd):
+        self._flat = _flat_from_state_dict(sd, self.layers)
+        if self._engine is not None:
+            self._engine.set_params(self._flat)
+
+    def _pull(self):
+        if self._engine is not None:
+            self._flat = self._engine.get_params()
+
+    # -- engine management ---------------------------------------------------------------------------------
+    def _config(self, **over) -> GPEConfig:
+        f = self._flavor
+        kw = dict(layers=self.layers, activation=f.activation, kinetic_coeff=f.kinetic, pot_scale=f.pot_scale,
+                  base_mode=(self.mode if getattr(self, "use_perturbation", True) else -1), base_deriv=f.base_deriv,
+                  gamma=float(self.gamma), perturb_scale=float(self.perturb_scale), w_sym=f.w_sym,
+                  sym_sign=(-1.0 if self.mode % 2 == 1 else 1.0))
+        kw.update(over)
+        return GPEConfig(**kw)
+
+    def _get_engine(self, **over) -> Engine:
+        key = tuple(sorted(over.items()))
+        if self._engine is None or key != self._engine_key:
+            if self._engine is not None:
+                self._pull()
+                self._engine.close()
+            self._engine = Engine(self._config(**over))
+            self._engine.set_params(self._flat)
+            self._engine_key = key
+        return self._engine
+
+    # -- reference methods ---------------------------------------------------------------------------------------
+    def forward(self, inputs):
+        return self._get_engine().forward(inputs)
+
+    __call__ = forward
+
+    def weighted_hermite(self, x, n):
+        """phi_n(x) (refine/...:95-119): evaluated by the engine's eval path with a zero perturbation."""
+        eng = self._get_engine()
+        x2 = x.reshape(-1, 1)
+        old = eng.cfg.perturb_scale
+        cfgm = eng.cfg.base_mode
+        if cfgm != n:
+            tmp = Engine(self._config(base_mode=int(n), perturb_scale=0.0))
+            tmp.set_params(self._flat)
+            sc, psi, _ = self._psi_only(tmp, x2)
+            tmp.close()
+            return psi.reshape(x.shape)
+        eng.set_perturb_scale(0.0)
+        sc, psi, _ = self._psi_only(eng, x2)
+        eng.set_perturb_scale(old)
+        return psi.reshape(x.shape)
+
+    @staticmethod
+    def _psi_only(eng, x2):
+        eng.bind_points(x2)
+        return eng.residual()
+
+    def get_complete_solution(self, x, perturbation, mode=None):
+        mode = self.mode if mode is None else mode
+        return self.weighted_hermite(x, mode) + perturbation
+
+    def compute_potential(self, x, potential_type="harmonic", **kwargs):
+        if potential_type not in _POT:
+            raise ValueError(f"Unknown potential type: {potential_type}")
+        f = self._flavor
+        if potential_type == "harmonic":
+            omega = kwargs.get("omega", 1.0)
+            return f.pot_scale * (omega * x) ** 2 if f is _NOTEBOOK else x ** 2
+        if potential_type == "gaussian":
+            return torch.exp(-(x - kwargs.get("a", 0.0)) ** 2)
+        V0, k = kwargs.get("V0", 1.0), kwargs.get("k", 2 * np.pi / 5.0)
+        return V0 * torch.cos(k * x) ** 2
+
+    def _scale_of(self, inputs, predictions):
+        """The reference passes `predictions` = s * forward(inputs) (s = q/normal_const or 1); recover s."""
+        nn_out = self.forward(inputs)
+        den = float((nn_out * nn_out).sum())
+        return float((predictions.detach() * nn_out).sum()) / den if den > 0 else 1.0
+
+    def _pde_eval(self, inputs, predictions, gamma, p, potential_type, precomputed_potential):
+        if precomputed_potential is None and potential_type not in _POT:
+            raise ValueError(f"Unknown potential type: {potential_type}")
+        pot = capi.POT_PRECOMPUTED if precomputed_potential is not None else _POT[potential_type]
+        s = self._scale_of(inputs, predictions)
+        eng = self._get_engine(potential=pot, p=int(p), w_bc=0.0)
+        eng.set_gamma(float(gamma))
+        eng.set_perturb_scale(s)
+        eng.bind_points(inputs, precomputed_potential)
+        return eng.residual()
+
+    def boundary_loss(self, boundary_points, boundary_values):
+        eng = self._get_engine()
+        if not hasattr(eng, "n_local"):
+            eng.bind_points(boundary_points)
+        eng.bind_boundary(boundary_points, boundary_values)
+        sc, _, _ = eng.residual(want_fields=False)
+        return torch.tensor(sc["bc"], dtype=torch.float32, device=_device())
+
+    def normalization_loss(self, u, dx):
+        integral = torch.sum(u ** 2) * dx
+        return (integral - 1.0) ** 2
+
+    def close(self):
+        if self._engine is not None:
+            self._pull()
+            self._engine.close()
+            self._engine = None
+
+
+class _RefinePINN(_PINNBase):
+    """refine/harmonic_pinn_simulation.py:52-217."""
+    _flavor = _REFINE
+
+    def __init__(self, layers, hbar=1.0, m=1.0, mode=0, gamma=1.0, use_perturbation=True):
+        super().__init__(layers, hbar, m, mode, gamma)
+        self.use_perturbation = use_perturbation
+
+    def pde_loss(self, inputs, predictions, gamma, p, potential_type="harmonic", precomputed_potential=None):
+        sc, _, _ = self._pde_eval(inputs, predictions, gamma, p, potential_type, precomputed_potential)
+        dev = _device()
+        return (torch.tensor(sc["pde"], dtype=torch.float32, device=dev),
+                torch.tensor(sc["mu"], dtype=torch.float32, device=dev))
+
+
+class _NotebookPINN(_PINNBase):
+    """Gross_Pitaevskii_1D_power_Test.ipynb c6."""
+    _flavor = _NOTEBOOK
+
+    def __init__(self, layers, hbar=1.0, m=1.0, mode=0, gamma=1.0, power=1.0):
+        super().__init__(layers, hbar, m, mode, gamma)
+        self.power = power
+        self.use_perturbation = True
+
+    def pde_loss(self, p, inputs, predictions, gamma, potential_type="harmonic", precomputed_potential=None):
+        sc, psi, res = self._pde_eval(inputs, predictions, gamma, p, potential_type, precomputed_potential)
+        dev = _device()
+        return (torch.tensor(sc["pde"], dtype=torch.float32, device=dev), res,
+                torch.tensor(sc["mu"], dtype=torch.float32, device=dev), psi)
+
+    def symmetry_loss(self, collocation_points, lb, ub):
+        eng = self._get_engine()
+        eng.bind_points(collocation_points)
+        sc, _, _ = eng.residual(want_fields=False)
+        return torch.tensor(sc["sym"], dtype=torch.float32, device=_device())
+
+
+def _as_np(X):
+    return X.detach().cpu().numpy() if isinstance(X, torch.Tensor) else np.asarray(X)
+
+
+def _history(eng: Engine, first: int, last: int, chunk: int = 8192):
+    out = []
+    s = first
+    while s <= last:
+        n = min(chunk, last - s + 1)
+        out += eng.read_history(s, n)
+        s += n
+    return out
+
+
+# ================================================================================================
+# refine flavour driver
+# ================================================================================================
+def _refine_advanced_initialization(m, mode):
+    m._flat = _advanced_init(m.layers, mode, "xavier_normal")
+    if m._engine is not None:
+        m._engine.set_params(m._flat)
+
+
+def _refine_train(gamma_values, modes, p, X_train, lb, ub, layers, epochs, tol, perturb_const,
+                  potential_type="harmonic", lr=1e-5, verbose=True, pretrain=None, chunk=500):
+    """train_gpe_model of refine/harmonic_pinn_simulation.py:220-430 (PL-PINN, gamma continuation).
+
+    Differences from the reference, all deliberate:
+      Q5  the reference "restores the best model" from a shallow state_dict copy, i.e. it keeps the LAST weights; so do we.
+      Q6  normal_const is taken at the first epoch of the first gamma of each mode (the reference only defines it when that
+          gamma is 0 and raises NameError otherwise).
+      pretraining (:300-303, row f2 of SURVEY 8) is done by `pretrain` if given (callable(model, mode, X_train)); otherwise
+      the gamma==0 start uses advanced_initialization like any other start.
+    Epoch bodies are enqueued `chunk` at a time with no host synchronisation; early stopping (:389-400) is evaluated on the
+    device after every update, so the stop epoch is exact.
+    """
+    if potential_type not in _POT:
+        raise ValueError(f"Unknown potential type: {potential_type}")
+    X = _as_np(X_train).astype(np.float64)
+    dx = X[1, 0] - X[0, 0]
+    dev = _device()
+    X_dev = torch.as_tensor(X.astype(np.float32), device=dev)
+    bpts = torch.tensor([[lb], [ub]], dtype=torch.float32, device=dev)
+    models_by_mode, mu_table, training_history, constant_history, epochs_history = {}, {}, {}, {}, {}
+    gamma_values = sorted(gamma_values)
+    if verbose:
+        print(f"Tolerance : {tol}, Perturbation constant : {perturb_const}")
+    for mode in modes:
+        if verbose:
+            print(f"\n===== Training for mode {mode} =====")
+        mu_logs, models_by_gamma, history_by_gamma, epochs_by_gamma = [], {}, {}, {}
+        prev_model = None
+        normal_const = None
+        for gamma in gamma_values:
+            if verbose:
+                print(f"\nTraining for γ = {gamma:.2f}, mode = {mode}, nonlinearity p = {p}")
+            model = _RefinePINN(layers, mode=mode, gamma=gamma)
+            if prev_model is not None:
+                model.load_state_dict(prev_model.state_dict())
+            elif gamma == 0.0 and pretrain is not None:
+                model = pretrain(model, mode, X_train)
+            else:
+                model.apply(lambda m: _refine_advanced_initialization(m, mode))
+            if normal_const is None:                                   # :333-335
+                nn0 = model.forward(X_dev)
+                normal_const = float(nn0.max())
+                constant_history[mode] = torch.tensor(normal_const)
+            model.perturb_scale = perturb_const / normal_const
+            eng = model._get_engine(potential=_POT[potential_type], p=int(p), dx=float(dx), lr=float(lr),
+                                    sched=capi.SCHED_COSINE_LOSS, T_0=200.0, T_mult=2.0, eta_min=1e-6,
+                                    w_bc=10.0, w_norm=20.0, stop_tol=float(tol), stop_patience=2000,
+                                    history_capacity=max(int(epochs), 1))
+            eng.bind_points(X_dev)
+            eng.bind_boundary(bpts)
+            done = 0
+            final_epoch = epochs
+            while done < epochs:
+                n = min(chunk, epochs - done)
+                eng.run(n)
+                done += n
+                stopped, stop_step = eng.stop_state()
+                if stopped:
+                    final_epoch = stop_step - 1                        # reference epochs are 0-based
+                    if verbose:
+                        print(f"Early stop at epoch {final_epoch}")
+                    break
+            n_rec = (final_epoch + 1) if final_epoch < epochs else epochs
+            hist = _history(eng, 1, n_rec)
+            loss_history = [h["loss"] for i, h in enumerate(hist) if i % 10 == 0]            # :375-376
+            lambda_history = [h["mu"] for i, h in enumerate(hist) if i % 100 == 0]           # :379-380
+            constraint_history = [10.0 * h["bc"] + 20.0 * h["norm"] for i, h in enumerate(hist) if i % 100 == 0]
+            if verbose:
+                for i, h in enumerate(hist):
+                    if i % 500 == 0:
+                        print(f"Epoch {i}, μ: {h['mu']:.4f}\nTotal Loss: {h['loss']:.6f}, PDE residual: {h['pde']:.6f}, "
+                              f"Constraints: {10.0 * h['bc'] + 20.0 * h['norm']:.6f}")
+            model._pull()
+            final_mu = lambda_history[-1] if lambda_history else 0                           # :407 (quirk Q5)
+            mu_logs.append((gamma, final_mu))
+            model.last_mu = hist[-1]["mu"] if hist else float("nan")
+            models_by_gamma[gamma] = model
+            history_by_gamma[gamma] = {"loss": loss_history, "constraint": constraint_history, "lambda": lambda_history}
+            epochs_by_gamma[gamma] = final_epoch
+            if prev_model is not None and prev_model is not model:
+                prev_model.close()
+            prev_model = model
+        if prev_model is not None:
+            prev_model.close()
+        mu_table[mode] = mu_logs
+        models_by_mode[mode] = models_by_gamma
+        training_history[mode] = history_by_gamma
+        epochs_history[mode] = epochs_by_gamma
+    return models_by_mode, mu_table, training_history, constant_history, epochs_history
+
+
+def _refine_wavefunction(model, X_test, constant, perturb_const, mode=None):
+    """plot_wavefunction's numerical part (refine/...:459-474): normalised u on the test grid, |u| for mode 0."""
+    X = _as_np(X_test).astype(np.float64)
+    dx = X[1, 0] - X[0, 0]
+    mode = model.mode if mode is None else mode
+    model.perturb_scale = float(perturb_const) / float(constant)
+    eng = model._get_engine()
+    eng.set_perturb_scale(model.perturb_scale)
+    u, dens = eng.eval_density(torch.as_tensor(X.astype(np.float32), device=_device()), float(dx), abs_flag=(mode == 0))
+    return u.cpu().numpy().ravel()
+
+
+# ================================================================================================
+# notebook flavour driver
+# ================================================================================================
+def _nb_advanced_initialization(m, mode):
+    m._flat = _advanced_init(m.layers, mode, "xavier_uniform")
+    if m._engine is not None:
+        m._engine.set_params(m._flat)
+
+
+def _nb_train(gamma_values, powers, modes, X_train, lb, ub, layers, epochs, potential_type="harmonic", lr=1e-3,
+              verbose=True, chunk=500):
+    """train_gpe_model of Gross_Pitaevskii_1D_power_Test.ipynb c10: loop modes x powers at gamma = gamma_values[0]."""
+    if potential_type not in _POT:
+        raise ValueError(f"Unknown potential type: {potential_type}")
+    gamma = gamma_values[0]                                            # c10:L34
+    X = _as_np(X_train).astype(np.float64)
+    dx = X[1, 0] - X[0, 0]
+    dev = _device()
+    X_dev = torch.as_tensor(X.astype(np.float32), device=dev)
+    bpts = torch.tensor([[lb], [ub]], dtype=torch.float32, device=dev)
+    models_by_mode, mu_table = {}, {}
+    powers = sorted(powers)
+    for mode in modes:
+        if verbose:
+            print(f"\n===== Training for mode {mode} =====")
+        mu_logs, models_by_power, prev_model = [], {}, None
+        for power in powers:
+            if verbose:
+                print(f"\nTraining for power = {power:.2f}, mode = {mode}")
+            model = _NotebookPINN(layers, mode=mode, power=power)
+            if prev_model is not None:
+                model.load_state_dict(prev_model.state_dict())
+            else:
+                model.apply(lambda m: _nb_advanced_initialization(m, mode))
+            model.gamma = gamma
+            eng = model._get_engine(potential=_POT[potential_type], p=int(power), dx=float(dx), lr=float(lr),
+                                    sched=capi.SCHED_PLATEAU, factor=0.5, patience=100, min_lr=1e-5,
+                                    w_bc=10.0, w_norm=20.0, history_capacity=max(int(epochs), 1))
+            eng.bind_points(X_dev)
+            eng.bind_boundary(bpts)
+            done = 0
+            while done < epochs:
+                n = min(chunk, epochs - done)
+                eng.run(n)
+                done += n
+            hist = _history(eng, 1, epochs)
+            lambda_history = [h["mu"] for i, h in enumerate(hist) if i % 100 == 0]           # c10:L106-108
+            if verbose:
+                for i, h in enumerate(hist):
+                    if i % 500 == 0:
+                        print(f"Epoch {i}, Loss: {h['loss']:.6f}, μ: {h['mu']:.4f}")
+            model._pull()
+            final_mu = lambda_history[-1] if lambda_history else 0
+            mu_logs.append((power, final_mu))
+            models_by_power[power] = model
+            if prev_model is not None:
+                prev_model.close()
+            prev_model = model
+        if prev_model is not None:
+            prev_model.close()
+        mu_table[mode] = mu_logs
+        models_by_mode[mode] = models_by_power
+    return models_by_mode, mu_table
+
+
+def _nb_density(model, X_test, mode=None):
+    """plot_wavefunction_densities' numerical part (nb c12:L30-42): normalised |psi|^2 on the test grid."""
+    X = _as_np(X_test).astype(np.float64)
+    dx = X[1, 0] - X[0, 0]
+    eng = model._get_engine()
+    u, dens = eng.eval_density(torch.as_tensor(X.astype(np.float32), device=_device()), float(dx), abs_flag=False)
+    return dens.cpu().numpy()
+
+
+refine = types.SimpleNamespace(GrossPitaevskiiPINN=_RefinePINN, train_gpe_model=_refine_train,
+                               advanced_initialization=_refine_advanced_initialization,
+                               normalized_wavefunction=_refine_wavefunction)
+notebook = types.SimpleNamespace(GrossPitaevskiiPINN=_NotebookPINN, train_gpe_model=_nb_train,
+                                 advanced_initialization=_nb_advanced_initialization, density=_nb_density)

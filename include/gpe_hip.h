@@ -87,6 +87,11 @@ typedef struct gpe_config {
     int32_t path;                 /* GPE_PATH_* */
     int32_t world_size;           /* data-parallel ranks sharing the replicated boundary batch (>=1) */
     int32_t history_capacity;     /* steps of scalar history kept on device (0: default 65536) */
+    /* early stopping, evaluated on the device after every update (refine/...:363-400): stop when loss <= stop_tol or
+     * after stop_patience steps without a new best loss; once stopped, further steps leave the parameters untouched.
+     * stop_tol <= 0 and stop_patience <= 0 disable the respective test. */
+    float stop_tol;
+    int32_t stop_patience;
 } gpe_config;
 
 /* Per-step scalars (refine/...:364-381 keeps loss every 10 and lambda every 100 epochs). */
@@ -162,6 +167,8 @@ int gpe_run(gpe_engine* e, int64_t n_steps);
 int gpe_read_scalars(gpe_engine* e, gpe_scalars* out);
 int gpe_read_history(gpe_engine* e, int64_t first_step, int64_t count, gpe_scalars* out);
 int gpe_synchronize(gpe_engine* e);
+/* early-stop state: *stopped = 1 once a stop condition fired; *stop_step = the optimiser step that fired it (1-based) */
+int gpe_stop_state(gpe_engine* e, int* stopped, int64_t* stop_step);
 
 /* ---- continuation knobs: the gamma / perturbation loop of refine/...:289-340 -------------------------- */
 int gpe_set_gamma(gpe_engine* e, float gamma);

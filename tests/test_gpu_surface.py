@@ -1,0 +1,93 @@
+"""The reference's Python surface re-hosted on the engine (gpe_pinn.surface): drop-in behaviour and end-to-end parity
+with a run of the reference's OWN train_gpe_model (golden fixture fx_nbdriver_small.npz)."""
+import numpy as np
+import pytest
+import torch
+
+import gpe_pinn
+from gpe_pinn import refine, notebook
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def test_notebook_driver_reproduces_reference_run():
+    """Same seed, same call as tests/golden/make_golden.py:notebook_driver_fixture -> same mu_table (fp32 trajectories
+    of 201 epochs drift apart slowly; 1e-2 relative on mu is far tighter than the differences between powers/modes)."""
+    fx = H.load_fx("fx_nbdriver_small.npz")
+    layers = [int(v) for v in fx["layers"]]
+    N, epochs = int(fx["N"]), int(fx["epochs"])
+    torch.manual_seed(int(fx["seed"]))
+    lb, ub = -10, 10
+    X = np.linspace(lb, ub, N).reshape(-1, 1)
+    models, mu_table = notebook.train_gpe_model([1], [2, 3], [0, 1], X, lb, ub, layers, epochs,
+                                                potential_type="harmonic", lr=1e-3, verbose=False)
+    for mode in (0, 1):
+        ref = fx[f"mu_mode{mode}"]
+        got = np.array(mu_table[mode], dtype=np.float64)
+        assert got.shape == ref.shape
+        np.testing.assert_array_equal(got[:, 0], ref[:, 0])                      # the powers
+        np.testing.assert_allclose(got[:, 1], ref[:, 1], rtol=1e-2)
+        for power in (2, 3):
+            w_ref = fx[f"flat_mode{mode}_p{power}"]
+            sd = models[mode][power].state_dict()
+            assert list(sd.keys()) == [f"network.{2 * k}.{n}" for k in range(len(layers) - 1) for n in ("weight", "bias")]
+            w = np.concatenate([v.numpy().ravel() for v in sd.values()])
+            assert np.abs(w - w_ref).max() < 0.05 and np.quantile(np.abs(w - w_ref), 0.9) < 5e-3
+    dens = notebook.density(models[0][3], np.linspace(lb, ub, 1000).reshape(-1, 1))
+    assert dens.shape == (1000,) and abs(dens.sum() * (20 / 999) - 1.0) < 1e-4
+
+
+def test_refine_driver_outputs_and_early_stop():
+    torch.manual_seed(0)
+    lb, ub, N = -10, 10, 400
+    X = np.linspace(lb, ub, N).reshape(-1, 1)
+    out = refine.train_gpe_model([0.0, 0.5], [0], 3, X, lb, ub, [1, 64, 64, 64, 1], 301, 1e-5, 0.01,
+                                 potential_type="harmonic", lr=1e-3, verbose=False)
+    models_by_mode, mu_table, training_history, constant_history, epochs_history = out
+    assert sorted(models_by_mode[0]) == [0.0, 0.5]
+    assert [g for g, _ in mu_table[0]] == [0.0, 0.5]
+    h = training_history[0][0.0]
+    assert len(h["loss"]) == 31 and len(h["lambda"]) == 4 and len(h["constraint"]) == 4     # every 10 / every 100 epochs
+    assert abs(mu_table[0][0][1] - 1.0) < 0.05                    # gamma = 0, refine convention: lambda_0 = 1
+    assert mu_table[0][1][1] > mu_table[0][0][1]                  # repulsive interaction raises mu
+    assert epochs_history[0][0.0] == 301
+    u = refine.normalized_wavefunction(models_by_mode[0][0.5], np.linspace(lb, ub, 1000).reshape(-1, 1),
+                                       constant_history[0], 0.01)
+    assert u.min() >= 0 and abs((u ** 2).sum() * (20 / 999) - 1) < 1e-4
+    # tolerance so loose that the first epoch already satisfies it: exact stop epoch 0
+    torch.manual_seed(0)
+    out = refine.train_gpe_model([0.0], [0], 3, X, lb, ub, [1, 64, 64, 64, 1], 50, 1e9, 0.01, lr=1e-3, verbose=False)
+    assert out[4][0][0.0] == 0 and len(out[2][0][0.0]["loss"]) == 1
+    with pytest.raises(ValueError):
+        refine.train_gpe_model([0.0], [0], 3, X, lb, ub, [1, 64, 64, 1], 5, 1e-5, 0.01, potential_type="morse")
+
+
+def test_class_surface_against_golden():
+    fx = H.load_fx("fx_refine_m0_g50_64x3.npz")
+    layers = [int(v) for v in fx["layers"]]
+    model = refine.GrossPitaevskiiPINN(layers, mode=int(fx["mode"]), gamma=float(fx["gamma"]))
+    sd = model.state_dict()
+    o = 0
+    for k, v in sd.items():
+        n = v.numel()
+        sd[k] = torch.from_numpy(fx["flat0"][o:o + n].reshape(v.shape).copy()); o += n
+    model.load_state_dict(sd)
+    X = torch.as_tensor(fx["x"], device="cuda")
+    nn_out = model.forward(X)
+    assert H.rel_err(nn_out.cpu().numpy(), fx["nn_out"]) < 1e-5
+    u_pred = float(fx["perturb_const"]) * nn_out / float(fx["normal_const"])
+    pde, lam = model.pde_loss(X, u_pred, float(fx["gamma"]), int(fx["p"]), "harmonic")
+    assert abs(float(lam) - float(fx["lam"])) < 2e-5 * abs(float(fx["lam"]))
+    assert abs(float(pde) - float(fx["pde_loss"])) < 2e-4 * float(fx["pde_loss"])
+    full = model.get_complete_solution(X, u_pred)
+    assert H.rel_err(full.cpu().numpy(), fx["u"]) < 5e-6
+    bl = model.boundary_loss(torch.tensor([[-10.0], [10.0]], device="cuda"), torch.zeros((2, 1), device="cuda"))
+    assert abs(float(bl) - float(fx["bc_loss"])) < 1e-5 * float(fx["bc_loss"]) + 1e-12
+    nl = model.normalization_loss(full, float(fx["dx"]))
+    assert abs(float(nl) - float(fx["norm_loss"])) < 1e-3 * max(float(fx["norm_loss"]), 1e-3)
+    with pytest.raises(ValueError):
+        model.compute_potential(X, "nope")
+    with pytest.raises(ValueError):
+        model.pde_loss(X, u_pred, 1.0, 3, "nope")
+    model.close()
