@@ -79,18 +79,28 @@ def cpu_baseline(wl, flat, budget_s=12.0, n_sample=8192):
     pb = go.Problem(layers=wl["layers"], gamma=wl["gamma"], p=3, kinetic_coeff=0.5, pot_scale=0.5, dx=dx,
                     w_bc=10.0, w_norm=20.0)
     trn = tr.TorchTrainer(pb, flat, xs, xb, lr=1e-3, sched=go.SCHED_CONST)
-    trn.step()                                   # warm-up
-    t0 = time.perf_counter()
-    n = 0
-    while True:
-        trn.step()
-        n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or n >= 200:
-            break
-    return dict(value=n * n_sample / el, unit="points/s", cores=int(torch.get_num_threads()), kind="port",
+    ncpu = os.cpu_count() or 1
+    best = None
+    sweep = sorted({1, min(8, ncpu), min(32, ncpu)})
+    for nt in sweep:                                   # thread sweep: small-tensor autograd rarely scales with cores
+        torch.set_num_threads(nt)
+        trn.step()                                     # warm-up
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            trn.step()
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s / len(sweep) or n >= 200:
+                break
+        rate = n * n_sample / el
+        if best is None or rate > best[0]:
+            best = (rate, nt, n, el)
+    rate, nt, n, el = best
+    return dict(value=rate, unit="points/s", cores=int(nt), kind="port", host_cpus=int(ncpu),
                 sample=f"{n} full training steps of the torch-autograd restatement (oracle/torch_ref.py, the reference's "
-                       f"op sequence) on a {n_sample}-point slice of the same workload, fp32, {el:.1f} s")
+                       f"op sequence) on a {n_sample}-point slice of the same workload, fp32, {el:.1f} s; best of a "
+                       f"thread sweep {sweep}")
 
 
 def main():
@@ -109,9 +119,11 @@ def main():
         args.gpus = world
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ          # under torchrun always take the RCCL path, even at world 1
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import gpe_pinn
     wl = WORKLOADS[args.workload]
@@ -129,7 +141,7 @@ def main():
     eng.bind_boundary(torch.as_tensor(xb, device=f"cuda:{local_rank}"))
 
     def run_steps(k):
-        if world == 1:
+        if not use_dist:
             eng.run(k)
         else:
             for _ in range(k):
@@ -138,16 +150,16 @@ def main():
     run_steps(args.warmup)
     eng.synchronize()
     eng.profile_enable(True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run_steps(args.steps)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -188,7 +200,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, flat)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -103,7 +103,8 @@ LIB_NAME = "libgpe_hip.so"
 
 
 def library_path() -> str:
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+    # GPE_HIP_LIB: alternative build of the SAME library (kernel-tuning experiments); never a different backend
+    return os.environ.get("GPE_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 
 _lib = None

@@ -77,8 +77,8 @@ GPE_DEV float gpe_tanh(float x) {
     p = fmaf(x2, p, 0.13333333333333333f);
     p = fmaf(x2, p, -0.33333333333333331f);
     p = fmaf(x2 * x, p, x);
-    float e = __expf(2.0f * ax);                 // v_exp_f32; +inf for large ax -> r = 1
-    float r = 1.0f - __fdividef(2.0f, e + 1.0f);
+    float e = __builtin_amdgcn_exp2f(ax * 2.8853900817779268f);   // exp(2|x|) as one v_exp_f32; +inf for large |x| -> r = 1
+    float r = fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);  // v_rcp_f32 (1 ulp)
     r = copysignf(r, x);
     return ax < 0.25f ? p : r;
 }

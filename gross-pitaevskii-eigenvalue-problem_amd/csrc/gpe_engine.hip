@@ -288,7 +288,7 @@ static unsigned fused_grid(gpe_engine* e, int64_t n) {
     return (unsigned)blocks;
 }
 
-static size_t fused_bwd_lds(gpe_engine* e) { return ((size_t)e->Ppad + 4 * 2 * 16 * F_PITCH) * sizeof(float); }
+static size_t fused_bwd_lds(gpe_engine* e, int C) { return ((size_t)e->Ppad + 4 * C * F_TILE) * sizeof(float); }
 
 static int ensure_packed(gpe_engine* e) {
     if (e->path != GPE_PATH_FUSED || !e->packed_dirty) return GPE_OK;
@@ -346,14 +346,14 @@ static int mlp_backward(gpe_engine* e, Batch& b) {
     if (b.n <= 0) return GPE_OK;
     if (e->path == GPE_PATH_FUSED) {
         unsigned grid = fused_grid(e, b.n);
-        size_t lds = fused_bwd_lds(e);
+        size_t lds = fused_bwd_lds(e, b.C);
         const bool mark = e->prof && (&b == &e->main);
         if (mark) prof_mark(e, 1, true);
         if (e->H == 64) { DISPATCH_C(b.C, launch_f_backward<64, CC>(e, b, grid, lds)); }
         else            { DISPATCH_C(b.C, launch_f_backward<32, CC>(e, b, grid, lds)); }
         if (mark) prof_mark(e, 1, false);
         HIPCHK(e, hipGetLastError());
-        hipLaunchKernelGGL(k_grad_reduce, dim3(cdiv(e->P, 256)), dim3(256), 0, e->stream, e->gslab, (int)grid, e->Ppad,
+        hipLaunchKernelGGL(k_grad_reduce, dim3(cdiv(e->P, 64)), dim3(1024), 0, e->stream, e->gslab, (int)grid, e->Ppad,
                            e->P, e->grad);
     } else {
         const NetDesc& nd = e->nd;
@@ -482,7 +482,7 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
     for (int i = 2; i < c.n_layers - 1; ++i) uniform = uniform && (c.layers[i] == c.layers[1]);
     const int H = c.layers[1];
     const int Lh = c.n_layers - 2;
-    size_t lds_need = ((size_t)e->Ppad + 4 * 2 * 16 * F_PITCH) * sizeof(float);
+    size_t lds_need = ((size_t)e->Ppad + 4 * (1 + 2 * dim) * F_TILE) * sizeof(float);
     bool fused_ok = uniform && (H == 32 || H == 64) && Lh >= 2 && lds_need <= 160 * 1024;
     if (c.path == GPE_PATH_FUSED && !fused_ok) CFAIL("fused path needs >=2 hidden layers of width 32 or 64 (and P*4 <= 160KB LDS)");
     e->path = (c.path == GPE_PATH_GENERIC || !fused_ok) ? GPE_PATH_GENERIC : GPE_PATH_FUSED;

@@ -28,6 +28,13 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef GPE_FWD_WAVES
+#define GPE_FWD_WAVES 2      // waves per SIMD the forward kernel is compiled for (C <= 5)
+#endif
+#ifndef GPE_BWD_WAVES
+#define GPE_BWD_WAVES 2
+#endif
+
 #define F_PITCH 20   // floats per row of a transposition tile (16 + 4 pad; rows stay 16-B aligned)
 
 GPE_DEV void wave_lds_fence() {
@@ -36,24 +43,34 @@ GPE_DEV void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// sum over the 16 lanes of a row (lanes with equal lane>>4); result valid in every lane of the row
+// sum over the 16 lanes of a DPP row (lanes with equal lane>>4); result valid in every lane of the row.
+// Four v_add_f32 with DPP operands (quad_perm xor1, xor2, row_half_mirror, row_mirror): no LDS, no waitcnt.
+template <int CTRL>
+GPE_DEV float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 GPE_DEV float row_sum16(float v) {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
+    v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);   // row_half_mirror
+    v += dpp_mov<0x140>(v);   // row_mirror
     return v;
 }
 
 // tile held point-on-lane (lane (m,q) reg r <-> row 4q+r, col m)  ->  feature-on-lane
 // (lane (i,q') element s <-> row i, col 4q'+s)
-GPE_DEV f32x4 tile_transpose(f32x4 v, float* T, int m, int q) {
+// C tiles at once through C wave-private LDS tiles: one fence pair per batch instead of per tile.
+#define F_TILE (16 * F_PITCH)
+template <int C>
+GPE_DEV void tiles_transpose(const f32x4 (&v)[C], f32x4 (&o)[C], float* T, int m, int q) {
     wave_lds_fence();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) T[(4 * q + r) * F_PITCH + m] = v[r];
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[c * F_TILE + (4 * q + r) * F_PITCH + m] = v[c][r];
     wave_lds_fence();
-    f32x4 o = *reinterpret_cast<const f32x4*>(&T[m * F_PITCH + 4 * q]);
-    return o;
+#pragma unroll
+    for (int c = 0; c < C; ++c) o[c] = *reinterpret_cast<const f32x4*>(&T[c * F_TILE + m * F_PITCH + 4 * q]);
 }
 
 // pack hidden-hidden weights (linear maps 1..L-1) in MFMA fragment order.
@@ -76,7 +93,7 @@ __global__ void k_pack_weights(NetDesc nd, int H, const float* __restrict__ thet
 }
 
 template <int H, int C, int NOUT>
-__global__ __launch_bounds__(256, (C <= 5 ? 2 : 1)) void f_forward(NetDesc nd, const float* __restrict__ theta,
+__global__ __launch_bounds__(256, (C <= 5 ? GPE_FWD_WAVES : 1)) void f_forward(NetDesc nd, const float* __restrict__ theta,
                                                                  const float* __restrict__ Wpk,
                                                                  const float* __restrict__ x, float* __restrict__ stored,
                                                                  float* __restrict__ O, int64_t N, int64_t ld,
@@ -199,7 +216,7 @@ __global__ __launch_bounds__(256, (C <= 5 ? 2 : 1)) void f_forward(NetDesc nd, c
 // Reverse pass.  Ob = dLoss/dO ([C][NOUT][ld]).  gslab: [gridDim.x][Ppad] per-workgroup gradient slabs.
 // Dynamic LDS: Ppad floats of gradient accumulators + 4 waves x 2 x 16 x F_PITCH floats transposition scratch.
 template <int H, int C, int NOUT>
-__global__ __launch_bounds__(256, (C <= 5 ? 2 : 1)) void f_backward(NetDesc nd, const float* __restrict__ theta,
+__global__ __launch_bounds__(256, (C <= 5 ? GPE_BWD_WAVES : 1)) void f_backward(NetDesc nd, const float* __restrict__ theta,
                                                                   const float* __restrict__ WpkT,
                                                                   const float* __restrict__ x,
                                                                   const float* __restrict__ stored,
@@ -210,8 +227,7 @@ __global__ __launch_bounds__(256, (C <= 5 ? 2 : 1)) void f_backward(NetDesc nd, 
     float* gacc = lds;
     const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4;
     const int wib = threadIdx.x >> 6;
-    float* TZ = lds + Ppad + wib * (2 * 16 * F_PITCH);
-    float* TX = TZ + 16 * F_PITCH;
+    float* TT = lds + Ppad + wib * (C * F_TILE);      // C transposition tiles, private to this wave
     const int L = nd.n_lin - 1;
     const int dim = nd.dim;
     const float shift = nd.shift;
@@ -285,10 +301,14 @@ __global__ __launch_bounds__(256, (C <= 5 ? 2 : 1)) void f_backward(NetDesc nd, 
         // ---- hidden -> hidden linear maps j = L-1 .. 1 ---------------------------------------------------
         for (int j = L - 1; j >= 1; --j) {
             // bias gradient of map j
+            {
+                float gb[NF];
 #pragma unroll
-            for (int f = 0; f < NF; ++f) {
-                float g = row_sum16(zb[0][f]);
-                if (m == 0) atomicAdd(&gacc[nd.offB[j] + 16 * (f >> 2) + 4 * q + (f & 3)], g);
+                for (int f = 0; f < NF; ++f) gb[f] = row_sum16(zb[0][f]);
+                if (m == 0) {
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) atomicAdd(&gacc[nd.offB[j] + 16 * (f >> 2) + 4 * q + (f & 3)], gb[f]);
+                }
             }
             // B1: adjoint of the input jets  Xb^T = W_j^T Zb^T
             const float* WT = WpkT + (size_t)(j - 1) * H * H;
@@ -344,21 +364,21 @@ __global__ __launch_bounds__(256, (C <= 5 ? 2 : 1)) void f_backward(NetDesc nd, 
                     for (int c = 0; c < C; ++c) xa[c][r] = a[c];
                 }
                 f32x4 xt[C];
-#pragma unroll
-                for (int c = 0; c < C; ++c) xt[c] = tile_transpose(xa[c], TX, m, q);
+                tiles_transpose<C>(xa, xt, TT, m, q);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
+                    f32x4 zv[C], zt[C];
+#pragma unroll
+                    for (int c = 0; c < C; ++c)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) zv[c][r] = zb[c][nt * 4 + r];
+                    tiles_transpose<C>(zv, zt, TT, m, q);
                     f32x4 dw = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int c = 0; c < C; ++c) {
-                        f32x4 zv;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) zv[r] = zb[c][nt * 4 + r];
-                        const f32x4 zt = tile_transpose(zv, TZ, m, q);
+                    for (int c = 0; c < C; ++c)
 #pragma unroll
                         for (int s = 0; s < 4; ++s)
-                            dw = __builtin_amdgcn_mfma_f32_16x16x4f32(zt[s], xt[c][s], dw, 0, 0, 0);
-                    }
+                            dw = __builtin_amdgcn_mfma_f32_16x16x4f32(zt[c][s], xt[c][s], dw, 0, 0, 0);
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         atomicAdd(&gacc[nd.offW[j] + (16 * nt + 4 * q + r) * H + 16 * kt + m], dw[r]);
@@ -403,11 +423,22 @@ __global__ __launch_bounds__(256, (C <= 5 ? 2 : 1)) void f_backward(NetDesc nd, 
     for (int i = threadIdx.x; i < Ppad; i += 256) slab[i] = gacc[i];
 }
 
-// grad[i] += sum_b gslab[b][i]   (fixed order -> the slab sum is deterministic)
-__global__ void k_grad_reduce(const float* __restrict__ gslab, int nslab, int Ppad, int P, float* __restrict__ grad) {
-    int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= P) return;
+// grad[i] += sum_b gslab[b][i].  Block = 64 parameters x 16 slab groups (1024 threads); fixed summation order, so the
+// slab sum is deterministic for a given grid.
+__global__ __launch_bounds__(1024) void k_grad_reduce(const float* __restrict__ gslab, int nslab, int Ppad, int P,
+                                                       float* __restrict__ grad) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int b = 0; b < nslab; ++b) s += gslab[(size_t)b * Ppad + i];
-    grad[i] += s;
+    if (i < P)
+        for (int b = g; b < nslab; b += 16) s += gslab[(size_t)b * Ppad + i];
+    red[g][lane] = s;
+    __syncthreads();
+    if (g == 0 && i < P) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][lane];
+        grad[i] += t;
+    }
 }
