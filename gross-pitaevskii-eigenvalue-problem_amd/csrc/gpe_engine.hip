@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <string>
@@ -184,6 +185,8 @@ struct gpe_engine {
     int nslab = 0;
     bool packed_dirty = true;
     bool ext_exchange = false;
+    bool fwd_wlds = false, bwd_wlds = false;      // hidden-hidden weights staged in LDS by the fused kernels
+    bool bwd_racc = false;                        // reverse kernel keeps the H x H weight gradients in registers (1 wave/SIMD)
     bool prof = false;
     std::vector<hipEvent_t> ev_pool;      // pairs: [2i] start, [2i+1] stop
     std::vector<int> ev_kind;             // 0 forward, 1 reverse
@@ -260,35 +263,58 @@ static int setup_batch(gpe_engine* e, Batch& b, const float* x, int64_t n, int C
         default: FAIL(e, GPE_ERR_INVALID, "bad channel count %d", Cv); \
     }
 
+#define F_LAUNCH(KERNEL, HH, CC, WL, GRID, BLOCK, LDS, ...)                                                    \
+    do {                                                                                                         \
+        if (e->nd.n_out == 1) hipLaunchKernelGGL((KERNEL<HH, CC, 1, WL>), dim3(GRID), dim3(BLOCK), LDS, e->stream, __VA_ARGS__); \
+        else                  hipLaunchKernelGGL((KERNEL<HH, CC, 2, WL>), dim3(GRID), dim3(BLOCK), LDS, e->stream, __VA_ARGS__); \
+    } while (0)
+#define B_LAUNCH(HH, CC, WL, NH, GRID, BLOCK, LDS, ...)                                                        \
+    do {                                                                                                         \
+        if (e->nd.n_out == 1) hipLaunchKernelGGL((f_backward<HH, CC, 1, WL, NH>), dim3(GRID), dim3(BLOCK), LDS, e->stream, __VA_ARGS__); \
+        else                  hipLaunchKernelGGL((f_backward<HH, CC, 2, WL, NH>), dim3(GRID), dim3(BLOCK), LDS, e->stream, __VA_ARGS__); \
+    } while (0)
+
+static size_t fused_w_bytes(gpe_engine* e) { return (size_t)(e->nd.n_lin - 2) * e->H * e->H * sizeof(float); }
+static size_t fused_fwd_lds(gpe_engine* e) { return (size_t)4 * e->H * sizeof(float) + (e->fwd_wlds ? fused_w_bytes(e) : 0); }
+
 template <int HH, int CC>
 static void launch_f_forward(gpe_engine* e, Batch& b, unsigned grid, int store) {
-    if (e->nd.n_out == 1)
-        hipLaunchKernelGGL((f_forward<HH, CC, 1>), dim3(grid), dim3(256), 0, e->stream, e->nd, e->theta, e->Wpk, b.x,
-                           b.stored, b.O, b.n, b.ld, store);
+    if (e->fwd_wlds)
+        F_LAUNCH(f_forward, HH, CC, true, grid, 256, fused_fwd_lds(e), e->nd, e->theta, e->Wpk, b.x, b.stored, b.O, b.n, b.ld, store);
     else
-        hipLaunchKernelGGL((f_forward<HH, CC, 2>), dim3(grid), dim3(256), 0, e->stream, e->nd, e->theta, e->Wpk, b.x,
-                           b.stored, b.O, b.n, b.ld, store);
+        F_LAUNCH(f_forward, HH, CC, false, grid, 256, fused_fwd_lds(e), e->nd, e->theta, e->Wpk, b.x, b.stored, b.O, b.n, b.ld, store);
 }
 template <int HH, int CC>
 static void launch_f_backward(gpe_engine* e, Batch& b, unsigned grid, size_t lds) {
-    if (e->nd.n_out == 1)
-        hipLaunchKernelGGL((f_backward<HH, CC, 1>), dim3(grid), dim3(256), lds, e->stream, e->nd, e->theta, e->WpkT,
-                           b.x, b.stored, b.Ob, e->gslab, b.n, b.ld, e->Ppad);
+#define BARGS e->nd, e->theta, e->WpkT, b.x, b.stored, b.Ob, e->gslab, b.n, b.ld, e->Ppad
+    if (e->bwd_racc) {
+        switch (e->nd.n_lin - 2) {
+            case 1: B_LAUNCH(HH, CC, true, 1, grid, 256, lds, BARGS); break;
+            case 2: B_LAUNCH(HH, CC, true, 2, grid, 256, lds, BARGS); break;
+            default: B_LAUNCH(HH, CC, true, 3, grid, 256, lds, BARGS); break;
+        }
+    } else if (e->bwd_wlds)
+        B_LAUNCH(HH, CC, true, 0, grid, 512, lds, BARGS);
     else
-        hipLaunchKernelGGL((f_backward<HH, CC, 2>), dim3(grid), dim3(256), lds, e->stream, e->nd, e->theta, e->WpkT,
-                           b.x, b.stored, b.Ob, e->gslab, b.n, b.ld, e->Ppad);
+        B_LAUNCH(HH, CC, false, 0, grid, 256, lds, BARGS);
+#undef BARGS
 }
 
-static unsigned fused_grid(gpe_engine* e, int64_t n) {
+// persistent grids: forward 256-thread blocks, 2 per CU; reverse 256-thread x 2 per CU, or 512-thread x 1 per CU (WLDS)
+static unsigned fused_grid(gpe_engine* e, int64_t n, int waves_per_block, int blocks_per_cu) {
     int64_t ntiles = (n + 15) / 16;
-    int64_t blocks = (ntiles + 3) / 4;
-    int64_t cap = (int64_t)e->num_cu * 2;
+    int64_t blocks = (ntiles + waves_per_block - 1) / waves_per_block;
+    int64_t cap = (int64_t)e->num_cu * blocks_per_cu;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (unsigned)blocks;
 }
 
-static size_t fused_bwd_lds(gpe_engine* e, int C) { return ((size_t)e->Ppad + 4 * C * F_TILE) * sizeof(float); }
+static size_t fused_bwd_lds(gpe_engine* e, int C) {
+    const int nwaves = e->bwd_racc ? 4 : (e->bwd_wlds ? 8 : 4);
+    const bool w = e->bwd_racc || e->bwd_wlds;
+    return ((size_t)e->Ppad + 8 * (size_t)e->H + (size_t)nwaves * C * F_TILE) * sizeof(float) + (w ? fused_w_bytes(e) : 0);
+}
 
 static int ensure_packed(gpe_engine* e) {
     if (e->path != GPE_PATH_FUSED || !e->packed_dirty) return GPE_OK;
@@ -322,7 +348,7 @@ static int mlp_forward(gpe_engine* e, Batch& b, bool store) {
     if (e->path == GPE_PATH_FUSED) {
         int rc = ensure_packed(e);
         if (rc) return rc;
-        unsigned grid = fused_grid(e, b.n);
+        unsigned grid = fused_grid(e, b.n, 4, 2);
         if (mark) prof_mark(e, 0, true);
         if (e->H == 64) { DISPATCH_C(b.C, launch_f_forward<64, CC>(e, b, grid, store ? 1 : 0)); }
         else            { DISPATCH_C(b.C, launch_f_forward<32, CC>(e, b, grid, store ? 1 : 0)); }
@@ -345,7 +371,7 @@ static int mlp_forward(gpe_engine* e, Batch& b, bool store) {
 static int mlp_backward(gpe_engine* e, Batch& b) {
     if (b.n <= 0) return GPE_OK;
     if (e->path == GPE_PATH_FUSED) {
-        unsigned grid = fused_grid(e, b.n);
+        unsigned grid = e->bwd_racc ? fused_grid(e, b.n, 4, 1) : (e->bwd_wlds ? fused_grid(e, b.n, 8, 1) : fused_grid(e, b.n, 4, 2));
         size_t lds = fused_bwd_lds(e, b.C);
         const bool mark = e->prof && (&b == &e->main);
         if (mark) prof_mark(e, 1, true);
@@ -482,7 +508,7 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
     for (int i = 2; i < c.n_layers - 1; ++i) uniform = uniform && (c.layers[i] == c.layers[1]);
     const int H = c.layers[1];
     const int Lh = c.n_layers - 2;
-    size_t lds_need = ((size_t)e->Ppad + 4 * (1 + 2 * dim) * F_TILE) * sizeof(float);
+    size_t lds_need = ((size_t)e->Ppad + 8 * (size_t)c.layers[1] + 4 * (1 + 2 * dim) * F_TILE) * sizeof(float);
     bool fused_ok = uniform && (H == 32 || H == 64) && Lh >= 2 && lds_need <= 160 * 1024;
     if (c.path == GPE_PATH_FUSED && !fused_ok) CFAIL("fused path needs >=2 hidden layers of width 32 or 64 (and P*4 <= 160KB LDS)");
     e->path = (c.path == GPE_PATH_GENERIC || !fused_ok) ? GPE_PATH_GENERIC : GPE_PATH_FUSED;
@@ -511,9 +537,26 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
         ok = alloc((void**)&e->Wpk, (size_t)(Lh - 1) * H * H * 4) && alloc((void**)&e->WpkT, (size_t)(Lh - 1) * H * H * 4) &&
              alloc((void**)&e->gslab, (size_t)e->nslab * e->Ppad * 4);
         if (ok) {
-            // allow > 64 KB dynamic LDS for the reverse kernels
-            int lds = (int)lds_need;
-#define SETLDS(HH, CC, NO) (void)hipFuncSetAttribute((const void*)f_backward<HH, CC, NO>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)
+            const int Cmain = 1 + 2 * dim;
+            const size_t wb = (size_t)(Lh - 1) * H * H * sizeof(float);
+            const char* env = getenv("GPE_WLDS");                     // tuning switch: 0 = weights from L2, 1 = from LDS
+            const bool want = env ? (atoi(env) != 0) : true;
+            e->fwd_wlds = want && wb + 16 * H <= 64 * 1024;
+            // reverse kernel: measured slower with 512-thread workgroups + LDS weights (5.40 vs 5.29 ms on NS): opt-in only
+            e->bwd_wlds = want && (!env || atoi(env) != 3) &&
+                          ((size_t)e->Ppad + 8 * (size_t)H + 8 * (size_t)Cmain * F_TILE) * sizeof(float) + wb <= 160 * 1024;
+            const char* envr = getenv("GPE_RACC");
+            e->bwd_racc = (!envr || atoi(envr) != 0) && (Lh - 1) >= 1 && (Lh - 1) <= 3 &&
+                          ((size_t)e->Ppad + 8 * (size_t)H + 4 * (size_t)Cmain * F_TILE) * sizeof(float) + wb <= 160 * 1024;
+            // allow > 64 KB dynamic LDS
+            const int lds_b = 160 * 1024, lds_f = 64 * 1024;
+#define SETLDS(HH, CC, NO)                                                                                                   \
+    (void)hipFuncSetAttribute((const void*)f_backward<HH, CC, NO, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
+    (void)hipFuncSetAttribute((const void*)f_backward<HH, CC, NO, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);  \
+    (void)hipFuncSetAttribute((const void*)f_backward<HH, CC, NO, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);  \
+    (void)hipFuncSetAttribute((const void*)f_backward<HH, CC, NO, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);  \
+    (void)hipFuncSetAttribute((const void*)f_backward<HH, CC, NO, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);  \
+    (void)hipFuncSetAttribute((const void*)f_forward<HH, CC, NO, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_f)
             SETLDS(64, 1, 1); SETLDS(64, 3, 1); SETLDS(64, 5, 1); SETLDS(64, 7, 1);
             SETLDS(64, 1, 2); SETLDS(64, 3, 2); SETLDS(64, 5, 2); SETLDS(64, 7, 2);
             SETLDS(32, 1, 1); SETLDS(32, 3, 1); SETLDS(32, 5, 1); SETLDS(32, 7, 1);
@@ -890,6 +933,16 @@ int gpe_stop_state(gpe_engine* e, int* stopped, int64_t* stop_step) {
     HIPCHK(e, hipStreamSynchronize(e->stream));
     if (stopped) *stopped = h.stopped;
     if (stop_step) *stop_step = h.stop_step;
+    return GPE_OK;
+}
+
+// diagnostic builds (-DGPE_STAMP) only: read and clear the per-phase cycle counters of the reverse kernel
+int gpe_debug_read_stamps(gpe_engine* e, unsigned long long out[16]) {
+    if (!e || !out) return GPE_ERR_INVALID;
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), 16 * sizeof(unsigned long long)));
+    unsigned long long z[16] = {0};
+    HIPCHK(e, hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z));
     return GPE_OK;
 }
 

@@ -92,7 +92,42 @@ __global__ void k_pack_weights(NetDesc nd, int H, const float* __restrict__ thet
     WpkT[idx] = W[(16 * b + 4 * q + s) * H + 16 * a + i];          // a = kt, b = nt
 }
 
-template <int H, int C, int NOUT>
+// ---- layer 0 helpers ---------------------------------------------------------------------------------------------
+// W0 ([H][dim], dim <= 3) and b0 are staged once per workgroup into LDS as w0s[4][H]: rows 0..2 = W0^T zero-padded to
+// three coordinates, row 3 = b0.  With the point coordinates zero-padded too, layer 0 is branch-free for any dim.
+template <int H>
+GPE_DEV void stage_layer0(float* w0s, const float* __restrict__ theta, const NetDesc& nd, int nthr) {
+    for (int i = threadIdx.x; i < 4 * H; i += nthr) {
+        const int k = i / H, n = i % H;
+        float v;
+        if (k == 3) v = theta[nd.offB[0] + n];
+        else v = (k < nd.dim) ? theta[nd.offW[0] + n * nd.dim + k] : 0.f;
+        w0s[i] = v;
+    }
+}
+
+// stored-equivalent (t, z_k, z_kk) of hidden layer 0 for features 16nt+4q+r, recomputed from the point coordinates
+template <int H, int C>
+GPE_DEV void layer0_st(const float* w0s, const float (&xv)[3], int nt, int q, f32x4 (&st)[C]) {
+    constexpr int D = (C - 1) / 2;
+    const int o = 16 * nt + 4 * q;
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(&w0s[o]);
+    const f32x4 w1 = *reinterpret_cast<const f32x4*>(&w0s[H + o]);
+    const f32x4 w2 = *reinterpret_cast<const f32x4*>(&w0s[2 * H + o]);
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(&w0s[3 * H + o]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float z = fmaf(w2[r], xv[2], fmaf(w1[r], xv[1], fmaf(w0[r], xv[0], bb[r])));
+        st[0][r] = gpe_tanh(z);
+        if constexpr (D >= 1) { st[1][r] = w0[r]; st[1 + D][r] = 0.f; }
+        if constexpr (D >= 2) { st[2][r] = w1[r]; st[2 + D][r] = 0.f; }
+        if constexpr (D >= 3) { st[3][r] = w2[r]; st[3 + D][r] = 0.f; }
+    }
+}
+
+// WLDS: the packed hidden-hidden weights ((L-1)*H*H floats) are staged once per workgroup into LDS and the MFMA A
+// operands are read from there (ds_read_b128, ~100 cycles) instead of from L2 (~600 cycles) right before each use.
+template <int H, int C, int NOUT, bool WLDS>
 __global__ __launch_bounds__(256, (C <= 5 ? GPE_FWD_WAVES : 1)) void f_forward(NetDesc nd, const float* __restrict__ theta,
                                                                  const float* __restrict__ Wpk,
                                                                  const float* __restrict__ x, float* __restrict__ stored,
@@ -105,9 +140,17 @@ __global__ __launch_bounds__(256, (C <= 5 ? GPE_FWD_WAVES : 1)) void f_forward(N
     const int64_t ntiles = (N + 15) >> 4;
     const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const float* W0 = theta + nd.offW[0];
-    const float* b0 = theta + nd.offB[0];
     const float shift = nd.shift;
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    float* w0s = lds_f;
+    float* lds_w = lds_f + 4 * H;
+    stage_layer0<H>(w0s, theta, nd, 256);
+    if constexpr (WLDS) {
+        const int n4 = (L - 1) * H * H / 4;
+        for (int i = threadIdx.x; i < n4; i += 256)
+            reinterpret_cast<f32x4*>(lds_w)[i] = reinterpret_cast<const f32x4*>(Wpk)[i];
+    }
+    __syncthreads();
 
     for (int64_t tile = wave0; tile < ntiles; tile += nwaves) {
         const int64_t pm = tile * 16 + m;
@@ -117,47 +160,42 @@ __global__ __launch_bounds__(256, (C <= 5 ? GPE_FWD_WAVES : 1)) void f_forward(N
 #pragma unroll
         for (int k = 0; k < 3; ++k) if (k < dim) xv[k] = x[pl * dim + k];
 
-        float a_in[C][NF];
+        float bufA[C][NF], bufB[C][NF];
         // ---- layer 0 (K = dim <= 3): VALU -----------------------------------------------------------
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
+            f32x4 st[C];
+            layer0_st<H, C>(w0s, xv, nt, q, st);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int n = 16 * nt + 4 * q + r;
-                float z = b0[n];
-                float wk[3] = {0.f, 0.f, 0.f};
+                float zk[D > 0 ? D : 1], zkk[D > 0 ? D : 1], a[C];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) if (k < dim) { wk[k] = W0[n * dim + k]; z = fmaf(wk[k], xv[k], z); }
-                float t = gpe_tanh(z);
-                float s = fmaf(-t, t, 1.0f);
-                a_in[0][nt * 4 + r] = t + shift;
+                for (int jd = 0; jd < D; ++jd) { zk[jd] = st[1 + jd][r]; zkk[jd] = 0.f; }
+                act_from_stored<D>(st[0][r], zk, zkk, shift, a);
 #pragma unroll
-                for (int j = 0; j < D; ++j) {
-                    a_in[1 + j][nt * 4 + r] = s * wk[j];
-                    a_in[1 + D + j][nt * 4 + r] = -2.0f * t * s * wk[j] * wk[j];
-                }
+                for (int c = 0; c < C; ++c) bufA[c][nt * 4 + r] = a[c];
             }
         }
-        // ---- hidden -> hidden layers on the matrix cores -------------------------------------------------
-        for (int j = 1; j < L; ++j) {
-            const float* Wp = Wpk + (size_t)(j - 1) * H * H;
+        // ---- hidden -> hidden layer j on the matrix cores: a_in -> a_out -------------------------------------
+        auto layer = [&](const float (&a_in)[C][NF], float (&a_out)[C][NF], int j) {
+            const float* Wp = (WLDS ? (const float*)lds_w : Wpk) + (size_t)(j - 1) * H * H;
             const float* bj = theta + nd.offB[j];
-            float a_out[C][NF];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
+                f32x4 w[NT];
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) w[kt] = *reinterpret_cast<const f32x4*>(&Wp[((nt * NT + kt) * 64 + lane) * 4]);
                 f32x4 acc[C];
                 acc[0] = *reinterpret_cast<const f32x4*>(&bj[16 * nt + 4 * q]);
 #pragma unroll
                 for (int c = 1; c < C; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kt = 0; kt < NT; ++kt) {
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(&Wp[((nt * NT + kt) * 64 + lane) * 4]);
+                for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
                     for (int s = 0; s < 4; ++s)
 #pragma unroll
                         for (int c = 0; c < C; ++c)
-                            acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s], a_in[c][kt * 4 + s], acc[c], 0, 0, 0);
-                }
+                            acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[kt][s], a_in[c][kt * 4 + s], acc[c], 0, 0, 0);
                 f32x4 tt;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -180,67 +218,113 @@ __global__ __launch_bounds__(256, (C <= 5 ? GPE_FWD_WAVES : 1)) void f_forward(N
                     for (int c = 1; c < C; ++c) *reinterpret_cast<f32x4*>(sp + (size_t)c * NT * 256) = acc[c];
                 }
             }
-#pragma unroll
-            for (int c = 0; c < C; ++c)
-#pragma unroll
-                for (int f = 0; f < NF; ++f) a_in[c][f] = a_out[c][f];
-        }
+        };
         // ---- output layer (n_out <= 2): VALU dot + reduction over the 4 q-lanes of a point ------------------
-        const float* Wo = theta + nd.offW[L];
-        const float* bo = theta + nd.offB[L];
+        auto output = [&](const float (&a_in)[C][NF]) {
+            const float* Wo = theta + nd.offW[L];
+            const float* bo = theta + nd.offB[L];
 #pragma unroll
-        for (int o = 0; o < NOUT; ++o) {
-            float part[C];
+            for (int o = 0; o < NOUT; ++o) {
+                float part[C];
 #pragma unroll
-            for (int c = 0; c < C; ++c) part[c] = 0.f;
+                for (int c = 0; c < C; ++c) part[c] = 0.f;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(&Wo[o * H + 16 * nt + 4 * q]);
+                for (int nt = 0; nt < NT; ++nt) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(&Wo[o * H + 16 * nt + 4 * q]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                    for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int c = 0; c < C; ++c) part[c] = fmaf(w[r], a_in[c][nt * 4 + r], part[c]);
+                        for (int c = 0; c < C; ++c) part[c] = fmaf(w[r], a_in[c][nt * 4 + r], part[c]);
+                }
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    float v = part[c];
+                    v += __shfl_xor(v, 16, 64);
+                    v += __shfl_xor(v, 32, 64);
+                    if (c == 0) v += bo[o];
+                    if (q == 0 && valid) O[((int64_t)c * NOUT + o) * ld + pm] = v;
+                }
             }
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                float v = part[c];
-                v += __shfl_xor(v, 16, 64);
-                v += __shfl_xor(v, 32, 64);
-                if (c == 0) v += bo[o];
-                if (q == 0 && valid) O[((int64_t)c * NOUT + o) * ld + pm] = v;
-            }
-        }
+        };
+        int j = 1;
+        for (; j + 1 < L; j += 2) { layer(bufA, bufB, j); layer(bufB, bufA, j + 1); }   // ping-pong: no register copies
+        if (j < L) { layer(bufA, bufB, j); output(bufB); }
+        else output(bufA);
     }
 }
 
+// ---- diagnostic build only (-DGPE_STAMP): per-phase cycle shares of the reverse kernel via s_memtime ---------------
+__device__ unsigned long long g_stamps[16];
+#ifdef GPE_STAMP
+GPE_DEV unsigned long long stamp_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define STAMP(i) do { unsigned long long _t = stamp_now(); st_acc[i] += _t - st_last; st_last = _t; } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 // Reverse pass.  Ob = dLoss/dO ([C][NOUT][ld]).  gslab: [gridDim.x][Ppad] per-workgroup gradient slabs.
-// Dynamic LDS: Ppad floats of gradient accumulators + 4 waves x 2 x 16 x F_PITCH floats transposition scratch.
-template <int H, int C, int NOUT>
-__global__ __launch_bounds__(256, (C <= 5 ? GPE_BWD_WAVES : 1)) void f_backward(NetDesc nd, const float* __restrict__ theta,
+// Dynamic LDS: gacc[Ppad] | g0[4H] (layer-0 gradients, padded) | nwaves x C transposition tiles | w0s[4H] | (WLDS) W^T.
+// WLDS: 512-thread workgroups (one per CU) that also keep the packed transposed weights in LDS.
+// NHH > 0 ("register accumulation"): the number of hidden-hidden maps is the compile-time constant NHH, the kernel runs
+// one wave per SIMD (256-thread workgroups, up to 512 registers per lane) and every wave keeps its share of ALL the
+// H x H weight gradients in MFMA accumulators across all the tiles it processes -- the products dW += Zb X^T chain
+// straight into them and LDS float atomics (measured at ~0.4 lane-adds per clock per CU: the limiter of the NHH = 0
+// variant) are used only for the small parameters and once per wave at the end.
+template <int H, int C, int NOUT, bool WLDS, int NHH>
+__global__ __launch_bounds__((NHH > 0 ? 256 : (WLDS ? 512 : 256)), (NHH > 0 ? 1 : (C <= 5 ? GPE_BWD_WAVES : 1))) void f_backward(NetDesc nd, const float* __restrict__ theta,
                                                                   const float* __restrict__ WpkT,
                                                                   const float* __restrict__ x,
                                                                   const float* __restrict__ stored,
                                                                   const float* __restrict__ Ob, float* __restrict__ gslab,
                                                                   int64_t N, int64_t ld, int Ppad) {
     constexpr int D = (C - 1) / 2, NT = H / 16, NF = NT * 4;
+    constexpr int NTHR = (NHH > 0) ? 256 : (WLDS ? 512 : 256);
+    constexpr bool RACC = NHH > 0;
+    static_assert(!RACC || WLDS, "register accumulation variant keeps W^T in LDS");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* gacc = lds;
+    float* g0 = lds + Ppad;
     const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4;
     const int wib = threadIdx.x >> 6;
-    float* TT = lds + Ppad + wib * (C * F_TILE);      // C transposition tiles, private to this wave
+    float* TT = g0 + 4 * H + wib * (C * F_TILE);      // C transposition tiles, private to this wave
+    float* w0s = g0 + 4 * H + (NTHR / 64) * (C * F_TILE);
+    float* lds_w = w0s + 4 * H;
     const int L = nd.n_lin - 1;
     const int dim = nd.dim;
     const float shift = nd.shift;
     const int64_t ntiles = (N + 15) >> 4;
     const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const float* W0 = theta + nd.offW[0];
-    const float* b0 = theta + nd.offB[0];
     const float* Wo = theta + nd.offW[L];
 
-    for (int i = threadIdx.x; i < Ppad; i += 256) gacc[i] = 0.f;
+    for (int i = threadIdx.x; i < Ppad + 4 * H; i += NTHR) gacc[i] = 0.f;      // gacc and g0 are contiguous
+    stage_layer0<H>(w0s, theta, nd, NTHR);
+    if constexpr (WLDS) {
+        const int n4 = (L - 1) * H * H / 4;
+        for (int i = threadIdx.x; i < n4; i += NTHR)
+            reinterpret_cast<f32x4*>(lds_w)[i] = reinterpret_cast<const f32x4*>(WpkT)[i];
+    }
     __syncthreads();
 
+    f32x4 dwacc[RACC ? NHH : 1][NT][NT];
+    if constexpr (RACC) {
+#pragma unroll
+        for (int a = 0; a < NHH; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+#pragma unroll
+                for (int c = 0; c < NT; ++c) dwacc[a][b][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#ifdef GPE_STAMP
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = stamp_now();
+#endif
     for (int64_t tile = wave0; tile < ntiles; tile += nwaves) {
         const int64_t pm = tile * 16 + m;
         const bool valid = pm < N;
@@ -254,18 +338,32 @@ __global__ __launch_bounds__(256, (C <= 5 ? GPE_BWD_WAVES : 1)) void f_backward(
 #pragma unroll
             for (int c = 0; c < C; ++c) ob[o][c] = valid ? Ob[((int64_t)c * NOUT + o) * ld + pm] : 0.f;
 
+        // stored (t, z_k, z_kk) of hidden layer h, feature tile kt: HBM for h >= 1, recomputed from x for h = 0
+        auto load_st = [&](int h, int kt, f32x4 (&st)[C]) {
+            if (h >= 1) {
+                const float* sp = stored + ((((size_t)tile * (L - 1) + (h - 1)) * C) * NT + kt) * 256 + lane * 4;
+#pragma unroll
+                for (int c = 0; c < C; ++c) st[c] = *reinterpret_cast<const f32x4*>(sp + (size_t)c * NT * 256);
+            } else {
+                layer0_st<H, C>(w0s, xv, kt, q, st);
+            }
+        };
+
         // ---- output layer: dWout, dbout, adjoint into the last hidden layer, activation adjoint --------
         float zb[C][NF];
         {
-            const float* sp0 = stored + (((size_t)tile * (L - 1) + (L - 2)) * C) * NT * 256 + lane * 4;
+            f32x4 stn[C];
+            load_st(L - 1, 0, stn);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 f32x4 st[C];
 #pragma unroll
-                for (int c = 0; c < C; ++c) st[c] = *reinterpret_cast<const f32x4*>(sp0 + ((size_t)c * NT + nt) * 256);
+                for (int c = 0; c < C; ++c) st[c] = stn[c];
+                if (nt + 1 < NT) load_st(L - 1, nt + 1, stn);            // prefetch: HBM latency behind this tile's math
                 f32x4 wo[NOUT];
 #pragma unroll
                 for (int o = 0; o < NOUT; ++o) wo[o] = *reinterpret_cast<const f32x4*>(&Wo[o * H + 16 * nt + 4 * q]);
+                float gw[NOUT][4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float zk[D > 0 ? D : 1], zkk[D > 0 ? D : 1], a[C], ab[C], zv[C];
@@ -277,8 +375,7 @@ __global__ __launch_bounds__(256, (C <= 5 ? GPE_BWD_WAVES : 1)) void f_backward(
                         float g = 0.f;
 #pragma unroll
                         for (int c = 0; c < C; ++c) g = fmaf(ob[o][c], a[c], g);
-                        g = row_sum16(g);
-                        if (m == 0) atomicAdd(&gacc[nd.offW[L] + o * H + 16 * nt + 4 * q + r], g);
+                        gw[o][r] = row_sum16(g);
                     }
 #pragma unroll
                     for (int c = 0; c < C; ++c) {
@@ -291,15 +388,26 @@ __global__ __launch_bounds__(256, (C <= 5 ? GPE_BWD_WAVES : 1)) void f_backward(
 #pragma unroll
                     for (int c = 0; c < C; ++c) zb[c][nt * 4 + r] = zv[c];
                 }
-            }
+                if (m == 0) {
 #pragma unroll
-            for (int o = 0; o < NOUT; ++o) {
-                float g = row_sum16(ob[o][0]);
-                if (lane == 0) atomicAdd(&gacc[nd.offB[L] + o], g);
+                    for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) atomicAdd(&gacc[nd.offW[L] + o * H + 16 * nt + 4 * q + r], gw[o][r]);
+                }
+            }
+            float gbo[NOUT];
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) gbo[o] = row_sum16(ob[o][0]);
+            if (lane == 0) {
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) atomicAdd(&gacc[nd.offB[L] + o], gbo[o]);
             }
         }
+        STAMP(0);
         // ---- hidden -> hidden linear maps j = L-1 .. 1 ---------------------------------------------------
-        for (int j = L - 1; j >= 1; --j) {
+        const int jtop = RACC ? NHH : (L - 1);
+#pragma unroll
+        for (int j = jtop; j >= 1; --j) {
             // bias gradient of map j
             {
                 float gb[NF];
@@ -310,117 +418,163 @@ __global__ __launch_bounds__(256, (C <= 5 ? GPE_BWD_WAVES : 1)) void f_backward(
                     for (int f = 0; f < NF; ++f) atomicAdd(&gacc[nd.offB[j] + 16 * (f >> 2) + 4 * q + (f & 3)], gb[f]);
                 }
             }
-            // B1: adjoint of the input jets  Xb^T = W_j^T Zb^T
-            const float* WT = WpkT + (size_t)(j - 1) * H * H;
-            float xb[C][NF];
+            // ---- (1) transpose Zb once: C*NT tiles, kept in registers for the weight-gradient products ------------
+            STAMP(1);
+            f32x4 zt[NT][C];
 #pragma unroll
-            for (int kt = 0; kt < NT; ++kt) {
-                f32x4 acc[C];
-#pragma unroll
-                for (int c = 0; c < C; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(&WT[((kt * NT + nt) * 64 + lane) * 4]);
-#pragma unroll
-                    for (int s = 0; s < 4; ++s)
-#pragma unroll
-                        for (int c = 0; c < C; ++c)
-                            acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s], zb[c][nt * 4 + s], acc[c], 0, 0, 0);
-                }
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 zv[C];
 #pragma unroll
                 for (int c = 0; c < C; ++c)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) xb[c][kt * 4 + r] = acc[c][r];
+                    for (int r = 0; r < 4; ++r) zv[c][r] = zb[c][nt * 4 + r];
+                tiles_transpose<C>(zv, zt[nt], TT, m, q);
             }
-            // B2 + activation adjoint of hidden layer j-1, one input feature tile kt at a time
-            const float* sp0 = stored + (((size_t)tile * (L - 1) + (j >= 2 ? j - 2 : 0)) * C) * NT * 256 + lane * 4;
+            STAMP(2);
+            // ---- (2) B1 in place, one channel at a time:  zb[c] <- W_j^T zb[c]  (adjoint of the input jets, before the
+            //      activation adjoint).  Per channel NT independent accumulators; the channel's input registers are dead
+            //      once its products are issued, so the result overwrites them: no second 16*C-register array.
+            const float* WT = (WLDS ? (const float*)lds_w : WpkT) + (size_t)(j - 1) * H * H;
 #pragma unroll
-            for (int kt = 0; kt < NT; ++kt) {
-                f32x4 st[C];
-                if (j >= 2) {
+            for (int c = 0; c < C; ++c) {
+                f32x4 acc[NT];
 #pragma unroll
-                    for (int c = 0; c < C; ++c) st[c] = *reinterpret_cast<const f32x4*>(sp0 + ((size_t)c * NT + kt) * 256);
-                } else {   // hidden layer 0: recompute from x
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int n = 16 * kt + 4 * q + r;
-                        float z = b0[n];
-                        float wk[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) if (k < dim) { wk[k] = W0[n * dim + k]; z = fmaf(wk[k], xv[k], z); }
-                        st[0][r] = gpe_tanh(z);
-#pragma unroll
-                        for (int jd = 0; jd < D; ++jd) { st[1 + jd][r] = wk[jd]; st[1 + D + jd][r] = 0.f; }
-                    }
-                }
-                f32x4 xa[C];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float zk[D > 0 ? D : 1], zkk[D > 0 ? D : 1], a[C];
-#pragma unroll
-                    for (int jd = 0; jd < D; ++jd) { zk[jd] = st[1 + jd][r]; zkk[jd] = st[1 + D + jd][r]; }
-                    act_from_stored<D>(st[0][r], zk, zkk, shift, a);
-#pragma unroll
-                    for (int c = 0; c < C; ++c) xa[c][r] = a[c];
-                }
-                f32x4 xt[C];
-                tiles_transpose<C>(xa, xt, TT, m, q);
+                for (int kt = 0; kt < NT; ++kt) acc[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    f32x4 zv[C], zt[C];
+                    f32x4 w[NT];
 #pragma unroll
-                    for (int c = 0; c < C; ++c)
+                    for (int kt = 0; kt < NT; ++kt) w[kt] = *reinterpret_cast<const f32x4*>(&WT[((kt * NT + nt) * 64 + lane) * 4]);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) zv[c][r] = zb[c][nt * 4 + r];
-                    tiles_transpose<C>(zv, zt, TT, m, q);
-                    f32x4 dw = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    for (int s = 0; s < 4; ++s)
 #pragma unroll
-                    for (int c = 0; c < C; ++c)
-#pragma unroll
-                        for (int s = 0; s < 4; ++s)
-                            dw = __builtin_amdgcn_mfma_f32_16x16x4f32(zt[c][s], xt[c][s], dw, 0, 0, 0);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        atomicAdd(&gacc[nd.offW[j] + (16 * nt + 4 * q + r) * H + 16 * kt + m], dw[r]);
+                        for (int kt = 0; kt < NT; ++kt)
+                            acc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[kt][s], zb[c][nt * 4 + s], acc[kt], 0, 0, 0);
                 }
-                // activation adjoint of hidden layer j-1 for this feature tile (overwrites xb in place)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float zk[D > 0 ? D : 1], zkk[D > 0 ? D : 1], ab[C], zv[C];
+                for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-                    for (int jd = 0; jd < D; ++jd) { zk[jd] = st[1 + jd][r]; zkk[jd] = st[1 + D + jd][r]; }
+                    for (int r = 0; r < 4; ++r) zb[c][kt * 4 + r] = acc[kt][r];
+            }
+            STAMP(5);
+            // ---- (3) one pass over the stored activations of hidden layer j-1 (read ONCE, next tile prefetched):
+            //      X recompute -> transpose -> B2 products dW_j += Zb X^T -> LDS accumulate; activation adjoint in place.
+            {
+                f32x4 stn[C];
+                load_st(j - 1, 0, stn);
 #pragma unroll
-                    for (int c = 0; c < C; ++c) ab[c] = xb[c][kt * 4 + r];
-                    act_adjoint<D>(st[0][r], zk, zkk, ab, zv);
+                for (int kt = 0; kt < NT; ++kt) {
+                    f32x4 st[C], xa[C], xt[C];
 #pragma unroll
-                    for (int c = 0; c < C; ++c) xb[c][kt * 4 + r] = zv[c];
+                    for (int c = 0; c < C; ++c) st[c] = stn[c];
+                    if (kt + 1 < NT) load_st(j - 1, kt + 1, stn);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float zk[D > 0 ? D : 1], zkk[D > 0 ? D : 1], a[C], ab[C], zv[C];
+#pragma unroll
+                        for (int jd = 0; jd < D; ++jd) { zk[jd] = st[1 + jd][r]; zkk[jd] = st[1 + D + jd][r]; }
+                        act_from_stored<D>(st[0][r], zk, zkk, shift, a);
+#pragma unroll
+                        for (int c = 0; c < C; ++c) { xa[c][r] = a[c]; ab[c] = zb[c][kt * 4 + r]; }
+                        act_adjoint<D>(st[0][r], zk, zkk, ab, zv);
+#pragma unroll
+                        for (int c = 0; c < C; ++c) zb[c][kt * 4 + r] = zv[c];
+                    }
+                    tiles_transpose<C>(xa, xt, TT, m, q);
+                    STAMP(3);
+                    if constexpr (RACC) {
+                        // chain into the persistent accumulators; NT independent chains interleaved
+#pragma unroll
+                        for (int c = 0; c < C; ++c)
+#pragma unroll
+                            for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt)
+                                    dwacc[RACC ? j - 1 : 0][nt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                        zt[nt][c][s2], xt[c][s2], dwacc[RACC ? j - 1 : 0][nt][kt], 0, 0, 0);
+                    } else
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        // two accumulators: v_mfma_f32_16x16x4_f32 has a 40-cycle dependent latency at a 32-cycle issue
+                        f32x4 dw0 = (f32x4){0.f, 0.f, 0.f, 0.f}, dw1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int c = 0; c < C; ++c) {
+                            dw0 = __builtin_amdgcn_mfma_f32_16x16x4f32(zt[nt][c][0], xt[c][0], dw0, 0, 0, 0);
+                            dw1 = __builtin_amdgcn_mfma_f32_16x16x4f32(zt[nt][c][1], xt[c][1], dw1, 0, 0, 0);
+                            dw0 = __builtin_amdgcn_mfma_f32_16x16x4f32(zt[nt][c][2], xt[c][2], dw0, 0, 0, 0);
+                            dw1 = __builtin_amdgcn_mfma_f32_16x16x4f32(zt[nt][c][3], xt[c][3], dw1, 0, 0, 0);
+                        }
+                        // LDS accumulate; columns XOR-swizzled by the row quad so that the 4 rows a wave touches per
+                        // instruction fall into different banks (undone when the slab is written)
+                        const int col = (16 * kt + m) ^ (((nt * 4 + q) & (NT - 1)) << 4);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            atomicAdd(&gacc[nd.offW[j] + (16 * nt + 4 * q + r) * H + col], dw0[r] + dw1[r]);
+                    }
+                    STAMP(4);
                 }
             }
-#pragma unroll
-            for (int c = 0; c < C; ++c)
-#pragma unroll
-                for (int f = 0; f < NF; ++f) zb[c][f] = xb[c][f];
         }
-        // ---- linear map 0: z = W0 x + b0, dz/dx_k = W0[:,k] ------------------------------------------------
+        // ---- linear map 0: z = W0 x + b0, dz/dx_k = W0[:,k]  ->  padded LDS area g0[n][4] = (dW0[n][0..2], db0[n]) -------
 #pragma unroll
-        for (int f = 0; f < NF; ++f) {
-            const int n = 16 * (f >> 2) + 4 * q + (f & 3);
-            float g = row_sum16(zb[0][f]);
-            if (m == 0) atomicAdd(&gacc[nd.offB[0] + n], g);
+        for (int nt = 0; nt < NT; ++nt) {
+            float g[4][4];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                if (k < dim) {
+            for (int r = 0; r < 4; ++r) {
+                const int f = nt * 4 + r;
+                g[r][3] = row_sum16(zb[0][f]);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
                     float v = zb[0][f] * xv[k];
                     if constexpr (C > 1) { if (k < D) v += zb[(1 + k) < C ? (1 + k) : 0][f]; }
-                    v = row_sum16(v);
-                    if (m == 0) atomicAdd(&gacc[nd.offW[0] + n * dim + k], v);
+                    g[r][k] = row_sum16(v);
                 }
             }
+            if (m == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) atomicAdd(&g0[(16 * nt + 4 * q + r) * 4 + k], g[r][k]);
+            }
         }
+        STAMP(6);
+    }
+#ifdef GPE_STAMP
+    if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_stamps[i], st_acc[i]);
+#endif
+    if constexpr (RACC) {      // once per wave: fold the register accumulators into the workgroup's LDS gradient (swizzled)
+#pragma unroll
+        for (int a = 0; a < NHH; ++a)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) {
+                    const int col = (16 * kt + m) ^ (((nt * 4 + q) & (NT - 1)) << 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        atomicAdd(&gacc[nd.offW[a + 1] + (16 * nt + 4 * q + r) * H + col], dwacc[a][nt][kt][r]);
+                }
     }
     __syncthreads();
     float* slab = gslab + (size_t)blockIdx.x * Ppad;
-    for (int i = threadIdx.x; i < Ppad; i += 256) slab[i] = gacc[i];
+    const int first = nd.offW[1];                       // layer-0 parameters occupy [0, (dim+1) H)
+    const int hid0 = nd.offW[1], hid1 = nd.offW[L];   // hidden-hidden maps 1..L-1 live in [hid0, hid1): H*H weights + H biases each
+    for (int i = first + threadIdx.x; i < Ppad; i += NTHR) {
+        int src = i;
+        if (i >= hid0 && i < hid1) {
+            const int e = (i - hid0) % (H * H + H);
+            if (e < H * H) {                                  // weight (n, k): stored at column k ^ swz(n)
+                const int n = e / H, k = e % H;
+                src = i - k + (k ^ ((((n >> 2)) & (NT - 1)) << 4));
+            }
+        }
+        slab[i] = gacc[src];
+    }
+    for (int i = threadIdx.x; i < 4 * H; i += NTHR) {
+        const int n = i >> 2, k = i & 3;
+        if (k == 3) slab[nd.offB[0] + n] = g0[i];
+        else if (k < dim) slab[nd.offW[0] + n * dim + k] = g0[i];
+    }
 }
 
 // grad[i] += sum_b gslab[b][i].  Block = 64 parameters x 16 slab groups (1024 threads); fixed summation order, so the
