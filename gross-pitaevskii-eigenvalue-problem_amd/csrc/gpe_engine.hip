@@ -731,9 +731,11 @@ int gpe_eval_density(gpe_engine* e, const float* d_x, int64_t n, float dx, int a
 }
 
 // ---- the step ------------------------------------------------------------------------------------------
+static unsigned head_grid(gpe_engine* e, int64_t n) { return (unsigned)std::min<int64_t>(cdiv(n, 256), (int64_t)e->num_cu * 2); }
+
 static int launch_head_pde(gpe_engine* e) {
     Batch& b = e->main;
-    dim3 g(cdiv(b.n, 256));
+    dim3 g(head_grid(e, b.n));
     DISPATCH_C(b.C, hipLaunchKernelGGL((k_head_pde<CC>), g, dim3(256), 0, e->stream, e->ph, e->base_norm, b.x, b.V, b.O,
                                         (const float* const*)e->orth_dev, b.u, b.Hu, e->sums(), b.n, b.ld));
     HIPCHK(e, hipGetLastError());
@@ -741,7 +743,7 @@ static int launch_head_pde(gpe_engine* e) {
 }
 static int launch_seed_pde(gpe_engine* e, float* d_resid, int want_seeds) {
     Batch& b = e->main;
-    dim3 g(cdiv(b.n, 256));
+    dim3 g(head_grid(e, b.n));
     DISPATCH_C(b.C, hipLaunchKernelGGL((k_seed_pde<CC>), g, dim3(256), 0, e->stream, e->ph, b.x, b.V,
                                         (const float* const*)e->orth_dev, b.u, b.Hu, e->sums(), b.Ob, d_resid, e->dsc(),
                                         b.n, b.ld, want_seeds));

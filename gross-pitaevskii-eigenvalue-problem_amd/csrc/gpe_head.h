@@ -29,9 +29,9 @@ __global__ __launch_bounds__(256) void k_head_pde(Phys ph, float base_norm, cons
                                                   int64_t ld) {
     constexpr int D = (C - 1) / 2;
     __shared__ double red[4];
-    int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
     double num = 0.0, den = 0.0, so[GPE_MAX_ORTH] = {0.0, 0.0, 0.0, 0.0};
-    if (m < N) {
+    // grid-stride: few workgroups, one double atomic each per sum (same-address atomics serialise at ~25 ns apiece)
+    for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < N; m += (int64_t)gridDim.x * 256) {
         float xv[3] = {0.f, 0.f, 0.f};
         for (int k = 0; k < ph.dim; ++k) xv[k] = x[m * ph.dim + k];
         float V = potential_at(ph, xv, Vpre, m);
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void k_head_pde(Phys ph, float base_norm, cons
             num += (double)(u * Hu[o]);
             den += (double)(u * u);
         }
-        for (int j = 0; j < ph.n_orth; ++j) so[j] = (double)(orth[j][m] * U[0][0]);
+        for (int j = 0; j < ph.n_orth; ++j) so[j] += (double)(orth[j][m] * U[0][0]);
     }
     double r = block_sum_256(num, red);
     if (threadIdx.x == 0) atomicAdd(&sums[S_NUM], r);
@@ -89,9 +89,8 @@ __global__ __launch_bounds__(256) void k_seed_pde(Phys ph, const float* __restri
                                                   int64_t ld, int want_seeds) {
     constexpr int D = (C - 1) / 2;
     __shared__ double red[4];
-    int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
     double sr2 = 0.0;
-    if (m < N) {
+    for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < N; m += (int64_t)gridDim.x * 256) {
         float lam = (float)(sums[S_NUM] / sums[S_DEN]);
         float I = (float)sums[S_DEN] * ph.dx;
         float xv[3] = {0.f, 0.f, 0.f};

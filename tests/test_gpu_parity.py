@@ -349,3 +349,20 @@ def test_tanh_accuracy_through_forward():
         ref, _ = go.mlp_forward(go.unflatten(flat.astype(np.float64), layers), x.astype(np.float64), 0, value_only=True)
         assert np.abs(got - ref[0]).max() < 2e-5          # sum of 32 tanh values, each good to ~3e-7
         eng.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5])
+def test_stored_reference_checkpoint_mu_table(mode):
+    """The reference's stored trained weights (fx_ckpt_harmonic_modes.npz, from harmonic_mode_zero_plot_data.pkl) through the
+    engine: lambda must match the mu_table the reference recorded (fp32 on both sides; tolerance 5e-5)."""
+    fx = H.load_fx("fx_ckpt_harmonic_modes.npz")
+    N = int(fx["N"])
+    x = np.linspace(float(fx["lb"]), float(fx["ub"]), N).reshape(-1, 1)
+    pb = go.Problem(layers=[int(v) for v in fx["layers"]], activation=1, kinetic_coeff=1.0, pot_scale=1.0, gamma=0.0, p=3,
+                    base_mode=mode, perturb_scale=float(fx["perturb_const"]) / float(fx[f"const_mode{mode}"]),
+                    dx=float(x[1, 0] - x[0, 0]), w_bc=0.0)
+    for path in ("generic", "fused"):
+        eng = make_engine(pb, fx[f"flat_mode{mode}"], x, None, path=PATHS[path])
+        sc, _, _ = eng.residual(want_fields=False)
+        assert abs(sc["mu"] - float(fx[f"mu_mode{mode}"])) < 5e-5, (path, sc["mu"])
+        eng.close()

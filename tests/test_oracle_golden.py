@@ -114,3 +114,18 @@ def test_q1_documented():
     """The 2D reference residual broadcasts to [N,N] (quirk Q1) -- the build follows the intended [N,1] formula."""
     fx = H.load_fx("fx_q1_2d_shape.npz")
     assert tuple(fx["residual_shape"]) == (7, 7)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5])
+def test_stored_reference_checkpoint_mu_table(mode):
+    """Known answer from the reference's own stored artefact (harmonic_mode_zero_plot_data.pkl): its trained weights must
+    reproduce the lambda it recorded (1, 3, 5, 7, 9, 11 to ~1e-5) through the oracle's forward path."""
+    fx = H.load_fx("fx_ckpt_harmonic_modes.npz")
+    N = int(fx["N"])
+    x = np.linspace(float(fx["lb"]), float(fx["ub"]), N).reshape(-1, 1)
+    pb = go.Problem(layers=[int(v) for v in fx["layers"]], activation=1, kinetic_coeff=1.0, pot_scale=1.0, gamma=0.0, p=3,
+                    base_mode=mode, perturb_scale=float(fx["perturb_const"]) / float(fx[f"const_mode{mode}"]),
+                    dx=float(x[1, 0] - x[0, 0]), w_bc=0.0)
+    res = go.loss_and_grad(pb, fx[f"flat_mode{mode}"].astype(np.float64), x, want_grad=False)
+    assert abs(res["lam"] - float(fx[f"mu_mode{mode}"])) < 3e-5
+    assert abs(res["lam"] - (2 * mode + 1)) < 5e-5
