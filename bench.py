@@ -176,6 +176,19 @@ def main():
         fwd_s = prof["fwd_ms"] / max(1, prof["fwd_launches"]) * 1e-3
         ach = 2.0 * f_fwd * n_local / bwd_s / 1e12 if bwd_s > 0 else 0.0
         ach_f = f_fwd * n_local / fwd_s / 1e12 if fwd_s > 0 else 0.0
+        # HBM bytes per launch of the dominant kernel from the committed PMC run of this same workload
+        # (profiles/r01/traffic_ns_v3.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 1/2-fetch correction applied)
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01", "traffic_ns_v3.json")
+        if args.workload == "ns_2d_4x64" and os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                for k, v in tj["kernels"].items():
+                    if "f_backward" in k:
+                        traffic = v["hbm_bytes_per_point"] * n_local
+                        traffic_src = "profiles/r01/traffic_ns_v3.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+            except Exception:
+                pass
         out = {
             "metric": "collocation-point residual evals/sec (full training step: jets fwd + residual + reverse + Adam)",
             "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -188,7 +201,8 @@ def main():
             "final_loss": sc["loss"], "final_mu": sc["mu"],
             "roofline": {"bound": "mfma", "kernel": "f_backward<64,5,1> (fused jet reverse pass)",
                          "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
+                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": (bmat_pt / 2.0 * (len(layers) - 3) / (len(layers) - 2) + 4.0 * (1 + 2 * layers[0]) + 4.0 * layers[0] + 8.0) * n_local,
                          "algorithmic_flop_per_point": 2.0 * f_fwd, "avg_launch_ms": bwd_s * 1e3,
                          "launches": prof["bwd_launches"]},
             "roofline_forward": {"bound": "mfma", "kernel": "f_forward<64,5,1>", "achieved": ach_f,
