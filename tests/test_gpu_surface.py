@@ -110,3 +110,20 @@ def test_end_to_end_mu_against_reference_notebook_output():
     mu = dict(mu_table[0])
     assert abs(mu[3] - 0.8948) < 3e-3, mu
     assert abs(mu[2] - 1.1125) < 3e-3, mu
+
+
+def test_gamma_continuation_against_independent_solver():
+    """PL-PINN gamma continuation (refine driver) vs the fp64 Newton/finite-difference solver oracle/gp_ground_state.py.
+    Full-length runs of the reference's 201-stage experiment are recorded in profiles/r01/accuracy_refine_*.json
+    (|lambda - exact| = 9e-6 at gamma = 100 with tol 1e-7); here a 5-stage prefix keeps the test to seconds."""
+    from oracle import gp_ground_state as gs
+    torch.manual_seed(0)
+    lb, ub, N = -10, 10, 4000
+    X = np.linspace(lb, ub, N).reshape(-1, 1)
+    gammas = [0.0, 0.5, 1.0, 1.5, 2.0]
+    out = refine.train_gpe_model(gammas, [0], 3, X, lb, ub, [1, 64, 64, 64, 1], 3001, 1e-7, 0.01, lr=1e-3, verbose=False)
+    models = out[0][0]
+    exact, _ = gs.ground_state_1d([0.0, 1.0, 2.0], c=1.0, vscale=1.0, n=2401)
+    for g in (0.0, 1.0, 2.0):
+        assert abs(models[g].last_mu - exact[g]) < 2e-3, (g, models[g].last_mu, exact[g])
+    assert abs(models[0.0].last_mu - 1.0) < 5e-5
