@@ -275,7 +275,11 @@ static int setup_batch(gpe_engine* e, Batch& b, const float* x, int64_t n, int C
     } while (0)
 
 static size_t fused_w_bytes(gpe_engine* e) { return (size_t)(e->nd.n_lin - 2) * e->H * e->H * sizeof(float); }
-static size_t fused_fwd_lds(gpe_engine* e) { return (size_t)4 * e->H * sizeof(float) + (e->fwd_wlds ? fused_w_bytes(e) : 0); }
+static size_t fused_small_bytes(gpe_engine* e) {       // = small_count() of gpe_fused.h, rounded up to 16 bytes
+    size_t n = (size_t)(4 + (e->nd.n_lin - 2) + e->nd.n_out) * e->H + 4;
+    return ((n + 3) & ~(size_t)3) * sizeof(float);
+}
+static size_t fused_fwd_lds(gpe_engine* e) { return fused_small_bytes(e) + (e->fwd_wlds ? fused_w_bytes(e) : 0); }
 
 template <int HH, int CC>
 static void launch_f_forward(gpe_engine* e, Batch& b, unsigned grid, int store) {
@@ -313,7 +317,8 @@ static unsigned fused_grid(gpe_engine* e, int64_t n, int waves_per_block, int bl
 static size_t fused_bwd_lds(gpe_engine* e, int C) {
     const int nwaves = e->bwd_racc ? 4 : (e->bwd_wlds ? 8 : 4);
     const bool w = e->bwd_racc || e->bwd_wlds;
-    return ((size_t)e->Ppad + 8 * (size_t)e->H + (size_t)nwaves * C * F_TILE) * sizeof(float) + (w ? fused_w_bytes(e) : 0);
+    return ((size_t)e->Ppad + 4 * (size_t)e->H + (size_t)nwaves * C * F_TILE) * sizeof(float) + fused_small_bytes(e) +
+           (w ? fused_w_bytes(e) : 0);
 }
 
 static int ensure_packed(gpe_engine* e) {
@@ -508,7 +513,7 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
     for (int i = 2; i < c.n_layers - 1; ++i) uniform = uniform && (c.layers[i] == c.layers[1]);
     const int H = c.layers[1];
     const int Lh = c.n_layers - 2;
-    size_t lds_need = ((size_t)e->Ppad + 8 * (size_t)c.layers[1] + 4 * (1 + 2 * dim) * F_TILE) * sizeof(float);
+    size_t lds_need = ((size_t)e->Ppad + (size_t)(8 + c.n_layers + 2) * c.layers[1] + 8 + 4 * (1 + 2 * dim) * F_TILE) * sizeof(float);
     bool fused_ok = uniform && (H == 32 || H == 64) && Lh >= 2 && lds_need <= 160 * 1024;
     if (c.path == GPE_PATH_FUSED && !fused_ok) CFAIL("fused path needs >=2 hidden layers of width 32 or 64 (and P*4 <= 160KB LDS)");
     e->path = (c.path == GPE_PATH_GENERIC || !fused_ok) ? GPE_PATH_GENERIC : GPE_PATH_FUSED;
@@ -541,13 +546,14 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
             const size_t wb = (size_t)(Lh - 1) * H * H * sizeof(float);
             const char* env = getenv("GPE_WLDS");                     // tuning switch: 0 = weights from L2, 1 = from LDS
             const bool want = env ? (atoi(env) != 0) : true;
-            e->fwd_wlds = want && wb + 16 * H <= 64 * 1024;
+            const size_t smallb = ((size_t)(4 + (Lh - 1) + no) * H + 8) * sizeof(float);
+            e->fwd_wlds = want && wb + smallb <= 64 * 1024;
             // reverse kernel: measured slower with 512-thread workgroups + LDS weights (5.40 vs 5.29 ms on NS): opt-in only
             e->bwd_wlds = want && (!env || atoi(env) != 3) &&
-                          ((size_t)e->Ppad + 8 * (size_t)H + 8 * (size_t)Cmain * F_TILE) * sizeof(float) + wb <= 160 * 1024;
+                          ((size_t)e->Ppad + 4 * (size_t)H + 8 * (size_t)Cmain * F_TILE) * sizeof(float) + smallb + wb <= 160 * 1024;
             const char* envr = getenv("GPE_RACC");
             e->bwd_racc = (!envr || atoi(envr) != 0) && (Lh - 1) >= 1 && (Lh - 1) <= 3 &&
-                          ((size_t)e->Ppad + 8 * (size_t)H + 4 * (size_t)Cmain * F_TILE) * sizeof(float) + wb <= 160 * 1024;
+                          ((size_t)e->Ppad + 4 * (size_t)H + 4 * (size_t)Cmain * F_TILE) * sizeof(float) + smallb + wb <= 160 * 1024;
             // allow > 64 KB dynamic LDS
             const int lds_b = 160 * 1024, lds_f = 64 * 1024;
 #define SETLDS(HH, CC, NO)                                                                                                   \

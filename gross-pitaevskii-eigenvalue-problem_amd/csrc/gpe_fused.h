@@ -95,8 +95,12 @@ __global__ void k_pack_weights(NetDesc nd, int H, const float* __restrict__ thet
 // ---- layer 0 helpers ---------------------------------------------------------------------------------------------
 // W0 ([H][dim], dim <= 3) and b0 are staged once per workgroup into LDS as w0s[4][H]: rows 0..2 = W0^T zero-padded to
 // three coordinates, row 3 = b0.  With the point coordinates zero-padded too, layer 0 is branch-free for any dim.
+// Behind it, in the same LDS block: the hidden biases b_1..b_{L-1} ([L-1][H]), the output weights ([n_out][H]) and the
+// output bias -- every small operand the per-tile code reads, so that no global (L2-latency) load sits inside a tile.
+GPE_DEV int small_count(const NetDesc& nd, int H) { return (4 + (nd.n_lin - 2) + nd.n_out) * H + 4; }
 template <int H>
 GPE_DEV void stage_layer0(float* w0s, const float* __restrict__ theta, const NetDesc& nd, int nthr) {
+    const int L = nd.n_lin - 1;
     for (int i = threadIdx.x; i < 4 * H; i += nthr) {
         const int k = i / H, n = i % H;
         float v;
@@ -104,6 +108,9 @@ GPE_DEV void stage_layer0(float* w0s, const float* __restrict__ theta, const Net
         else v = (k < nd.dim) ? theta[nd.offW[0] + n * nd.dim + k] : 0.f;
         w0s[i] = v;
     }
+    for (int i = threadIdx.x; i < (L - 1) * H; i += nthr) w0s[4 * H + i] = theta[nd.offB[1 + i / H] + i % H];
+    for (int i = threadIdx.x; i < nd.n_out * H; i += nthr) w0s[(4 + L - 1) * H + i] = theta[nd.offW[L] + i];
+    for (int i = threadIdx.x; i < nd.n_out; i += nthr) w0s[(4 + L - 1 + nd.n_out) * H + i] = theta[nd.offB[L] + i];
 }
 
 // stored-equivalent (t, z_k, z_kk) of hidden layer 0 for features 16nt+4q+r, recomputed from the point coordinates
@@ -143,7 +150,7 @@ __global__ __launch_bounds__(256, (C <= 5 ? GPE_FWD_WAVES : 1)) void f_forward(N
     const float shift = nd.shift;
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
     float* w0s = lds_f;
-    float* lds_w = lds_f + 4 * H;
+    float* lds_w = lds_f + ((small_count(nd, H) + 3) & ~3);
     stage_layer0<H>(w0s, theta, nd, 256);
     if constexpr (WLDS) {
         const int n4 = (L - 1) * H * H / 4;
@@ -179,7 +186,7 @@ __global__ __launch_bounds__(256, (C <= 5 ? GPE_FWD_WAVES : 1)) void f_forward(N
         // ---- hidden -> hidden layer j on the matrix cores: a_in -> a_out -------------------------------------
         auto layer = [&](const float (&a_in)[C][NF], float (&a_out)[C][NF], int j) {
             const float* Wp = (WLDS ? (const float*)lds_w : Wpk) + (size_t)(j - 1) * H * H;
-            const float* bj = theta + nd.offB[j];
+            const float* bj = w0s + (4 + (j - 1)) * H;          // LDS copy of b_j
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 f32x4 w[NT];
@@ -221,8 +228,8 @@ __global__ __launch_bounds__(256, (C <= 5 ? GPE_FWD_WAVES : 1)) void f_forward(N
         };
         // ---- output layer (n_out <= 2): VALU dot + reduction over the 4 q-lanes of a point ------------------
         auto output = [&](const float (&a_in)[C][NF]) {
-            const float* Wo = theta + nd.offW[L];
-            const float* bo = theta + nd.offB[L];
+            const float* Wo = w0s + (4 + L - 1) * H;            // LDS copies of W_out, b_out
+            const float* bo = w0s + (4 + L - 1 + NOUT) * H;
 #pragma unroll
             for (int o = 0; o < NOUT; ++o) {
                 float part[C];
@@ -294,14 +301,14 @@ __global__ __launch_bounds__((NHH > 0 ? 256 : (WLDS ? 512 : 256)), (NHH > 0 ? 1 
     const int wib = threadIdx.x >> 6;
     float* TT = g0 + 4 * H + wib * (C * F_TILE);      // C transposition tiles, private to this wave
     float* w0s = g0 + 4 * H + (NTHR / 64) * (C * F_TILE);
-    float* lds_w = w0s + 4 * H;
+    float* lds_w = w0s + ((small_count(nd, H) + 3) & ~3);
     const int L = nd.n_lin - 1;
     const int dim = nd.dim;
     const float shift = nd.shift;
     const int64_t ntiles = (N + 15) >> 4;
     const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const float* Wo = theta + nd.offW[L];
+    const float* Wo = w0s + (4 + L - 1) * H;                // LDS copy of W_out
 
     for (int i = threadIdx.x; i < Ppad + 4 * H; i += NTHR) gacc[i] = 0.f;      // gacc and g0 are contiguous
     stage_layer0<H>(w0s, theta, nd, NTHR);
