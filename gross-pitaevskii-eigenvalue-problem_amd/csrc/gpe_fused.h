@@ -159,13 +159,22 @@ __global__ __launch_bounds__(256, (C <= 5 ? GPE_FWD_WAVES : 1)) void f_forward(N
     }
     __syncthreads();
 
+    // point coordinates of the first tile; inside the loop the NEXT tile's are requested before this tile's math
+    float xn[3] = {0.f, 0.f, 0.f};
+    if (wave0 < ntiles) {
+        const int64_t p0 = min(wave0 * 16 + m, N - 1);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) if (k < dim) xn[k] = x[p0 * dim + k];
+    }
     for (int64_t tile = wave0; tile < ntiles; tile += nwaves) {
         const int64_t pm = tile * 16 + m;
         const bool valid = pm < N;
-        const int64_t pl = valid ? pm : N - 1;
-        float xv[3] = {0.f, 0.f, 0.f};
+        float xv[3] = {xn[0], xn[1], xn[2]};
+        if (tile + nwaves < ntiles) {
+            const int64_t pn = min((tile + nwaves) * 16 + m, N - 1);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) if (k < dim) xv[k] = x[pl * dim + k];
+            for (int k = 0; k < 3; ++k) if (k < dim) xn[k] = x[pn * dim + k];
+        }
 
         float bufA[C][NF], bufB[C][NF];
         // ---- layer 0 (K = dim <= 3): VALU -----------------------------------------------------------
