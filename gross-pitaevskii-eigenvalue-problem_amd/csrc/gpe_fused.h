@@ -451,26 +451,36 @@ __global__ __launch_bounds__((NHH > 0 ? 256 : (WLDS ? 512 : 256)), (NHH > 0 ? 1 
             //      activation adjoint).  Per channel NT independent accumulators; the channel's input registers are dead
             //      once its products are issued, so the result overwrites them: no second 16*C-register array.
             const float* WT = (WLDS ? (const float*)lds_w : WpkT) + (size_t)(j - 1) * H * H;
+            // KTG accumulators at a time (2 independent MFMA chains cover the 40-cycle dependent latency at a 32-cycle issue);
+            // a channel's outputs go to a small buffer because its input registers stay live until the last group.
+            constexpr int KTG = (NT >= 2) ? 2 : 1;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                f32x4 acc[NT];
+                f32x4 res[NT];
 #pragma unroll
-                for (int kt = 0; kt < NT; ++kt) acc[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int k0 = 0; k0 < NT; k0 += KTG) {
+                    f32x4 acc[KTG];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    f32x4 w[NT];
+                    for (int i = 0; i < KTG; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int kt = 0; kt < NT; ++kt) w[kt] = *reinterpret_cast<const f32x4*>(&WT[((kt * NT + nt) * 64 + lane) * 4]);
+                    for (int nt = 0; nt < NT; ++nt) {
+                        f32x4 w[KTG];
 #pragma unroll
-                    for (int s = 0; s < 4; ++s)
+                        for (int i = 0; i < KTG; ++i)
+                            w[i] = *reinterpret_cast<const f32x4*>(&WT[(((k0 + i) * NT + nt) * 64 + lane) * 4]);
 #pragma unroll
-                        for (int kt = 0; kt < NT; ++kt)
-                            acc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[kt][s], zb[c][nt * 4 + s], acc[kt], 0, 0, 0);
+                        for (int s = 0; s < 4; ++s)
+#pragma unroll
+                            for (int i = 0; i < KTG; ++i)
+                                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i][s], zb[c][nt * 4 + s], acc[i], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < KTG; ++i) res[k0 + i] = acc[i];
                 }
 #pragma unroll
                 for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) zb[c][kt * 4 + r] = acc[kt][r];
+                    for (int r = 0; r < 4; ++r) zb[c][kt * 4 + r] = res[kt][r];
             }
             STAMP(5);
             // ---- (3) one pass over the stored activations of hidden layer j-1 (read ONCE, next tile prefetched):
