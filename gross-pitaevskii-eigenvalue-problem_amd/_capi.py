@@ -89,6 +89,11 @@ SYMBOLS = {
     "gpe_read_history": (_int, [_vp, _i64, _i64, _P(gpe_scalars)]),
     "gpe_synchronize": (_int, [_vp]),
     "gpe_stop_state": (_int, [_vp, _P(_int), _P(_i64)]),
+    "gpe_bind_target": (_int, [_vp, _vp]),
+    "gpe_mse_begin": (_int, [_vp]),
+    "gpe_mse_update": (_int, [_vp]),
+    "gpe_mse_step": (_int, [_vp, _P(gpe_scalars)]),
+    "gpe_mse_loss_grad": (_int, [_vp, _P(C.c_double)]),
     "gpe_set_gamma": (_int, [_vp, _f]),
     "gpe_set_power": (_int, [_vp, _int]),
     "gpe_set_lr": (_int, [_vp, _f]),

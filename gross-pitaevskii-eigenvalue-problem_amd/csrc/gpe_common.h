@@ -41,7 +41,7 @@ enum { S_NUM = 0, S_DEN = 1, S_SYM = 2, S_ORTH0 = 3, /* ..S_ORTH0+3 */ S_COUNT =
 // Local (replicated, never exchanged) double scalars.
 enum { LS_BC_SE2 = 0, LS_BC_CNT = 1, LS_COUNT = 4 };
 // Tail of the float gradient exchange buffer.
-enum { GT_SUM_R2 = 0, GT_COUNT = 4 };
+enum { GT_SUM_R2 = 0, GT_MSE_SE2 = 1, GT_COUNT = 4 };
 
 // Optimiser / scheduler state living on the device (one struct; updated by k_update).
 struct OptDev {

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(1024) void k_update(int P, float* __restrict__ thet
                                                   const double* __restrict__ sums, const double* __restrict__ lsums,
                                                   Phys ph, OptCfg oc, OptDev* __restrict__ od,
                                                   gpe_scalars* __restrict__ hist, int cap, gpe_scalars* __restrict__ last,
-                                                  double bc_cnt, int do_update) {
+                                                  double bc_cnt, int do_update, int mse_mode) {
     __shared__ double red[16];
     __shared__ float s_coef, s_ss, s_b2s;
     __shared__ int s_skip;
@@ -79,12 +79,16 @@ __global__ __launch_bounds__(1024) void k_update(int P, float* __restrict__ thet
         double orth = 0.0;
         for (int j = 0; j < ph.n_orth; ++j) { double oj = sums[S_ORTH0 + j] * ph.dx; orth += oj * oj; }
         double loss = ph.w_pde * pde + ph.w_bc * bc + ph.w_norm * nrm + ph.w_sym * sym + ph.w_orth * orth;
+        if (mse_mode) {           // pre-training: loss = mean((NN - target)^2); plain Adam (no clip, no scheduler, no early stop)
+            loss = (double)grad[P + GT_MSE_SE2] / (ph.n_global * ph.n_out);
+            lam = 0.0; pde = 0.0; nrm = 0.0; bc = 0.0; sym = 0.0; orth = 0.0;
+        }
         int skip = !(isfinite(loss) && isfinite(gn));
         const int frozen = do_update && od->stopped;
         long long step = od->step + (do_update && !skip && !frozen ? 1 : 0);
         double lr = od->lr;
         float coef = 1.0f;
-        if (oc.clip_norm > 0.f) coef = (float)fmin(1.0, (double)oc.clip_norm / (gn + 1e-6));
+        if (oc.clip_norm > 0.f && !mse_mode) coef = (float)fmin(1.0, (double)oc.clip_norm / (gn + 1e-6));
         double bc1 = 1.0 - pow((double)oc.beta1, (double)step);
         double bc2 = 1.0 - pow((double)oc.beta2, (double)step);
         s_coef = coef;
@@ -100,6 +104,8 @@ __global__ __launch_bounds__(1024) void k_update(int P, float* __restrict__ thet
             if (!skip) {
                 hist[(step - 1) % cap] = r;
                 od->step = step;
+                if (mse_mode) { /* no scheduler / early-stop bookkeeping while pre-training */ }
+                else {
                 // early stopping bookkeeping (refine/...:366-372, 389-400)
                 if (loss < od->es_best) { od->es_best = loss; od->es_count = 0; } else od->es_count += 1;
                 if ((oc.stop_tol > 0.f && loss <= (double)oc.stop_tol) ||
@@ -125,6 +131,7 @@ __global__ __launch_bounds__(1024) void k_update(int P, float* __restrict__ thet
                         od->num_bad = 0;
                     }
                 }
+                }
             } else {
                 od->nonfinite = 1;
             }
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(1024) void k_update(int P, float* __restrict__ thet
     }
 }
 
-__global__ void k_tail(float* grad_tail, const double* dsc) { grad_tail[GT_SUM_R2] = (float)dsc[0]; }
+__global__ void k_tail(float* grad_tail, const double* dsc) { grad_tail[GT_SUM_R2] = (float)dsc[0]; grad_tail[GT_MSE_SE2] = (float)dsc[2]; }
 
 // ------------------------------------------------------------------------------------------------
 struct Batch {
@@ -193,8 +200,9 @@ struct gpe_engine {
     size_t ev_used = 0;
     const float** orth_dev = nullptr;
     const float* orth_host[GPE_MAX_ORTH] = {nullptr, nullptr, nullptr, nullptr};
-    Batch main, bc, sym, aux;
+    Batch main, bc, sym, aux, mse;
     const float* bc_target = nullptr;
+    const float* mse_target = nullptr;
     int num_cu = 256;
     int phase = 0;                 // 0 idle, 1 after begin, 2 after backward
     std::string err;
@@ -582,7 +590,7 @@ void gpe_destroy(gpe_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
-    free_batch(e->main); free_batch(e->bc); free_batch(e->sym); free_batch(e->aux);
+    free_batch(e->main); free_batch(e->bc); free_batch(e->sym); free_batch(e->aux); free_batch(e->mse);
     for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
     if (e->ext_exchange) { e->grad = nullptr; e->dbl = nullptr; }
     void* ps[] = {e->theta, e->am, e->av, e->grad, e->dbl, e->od, e->hist, e->last, (void*)e->orth_dev, e->Wpk, e->WpkT, e->gslab};
@@ -811,10 +819,69 @@ int gpe_step_update(gpe_engine* e) {
     if (!e) return GPE_ERR_INVALID;
     if (e->phase != 2) FAIL(e, GPE_ERR_STATE, "step_update without step_backward");
     hipLaunchKernelGGL(k_update, dim3(1), dim3(1024), 0, e->stream, e->P, e->theta, e->am, e->av, e->grad, e->sums(),
-                       e->lsums(), e->ph, e->oc, e->od, e->hist, e->cap, e->last, bc_count(e), 1);
+                       e->lsums(), e->ph, e->oc, e->od, e->hist, e->cap, e->last, bc_count(e), 1, 0);
     HIPCHK(e, hipGetLastError());
     e->packed_dirty = true;
     e->phase = 0;
+    return GPE_OK;
+}
+
+// ---- pre-training on an analytic target (refine/harmonic_pinn_simulation.py:650-701) ---------------------------------
+int gpe_bind_target(gpe_engine* e, const float* d_target) {
+    if (!e) return GPE_ERR_INVALID;
+    if (e->main.n <= 0) FAIL(e, GPE_ERR_STATE, "bind_target before bind_points");
+    e->mse_target = d_target;
+    if (!d_target) { free_batch(e->mse); return GPE_OK; }
+    return setup_batch(e, e->mse, e->main.x, e->main.n, 1, false, nullptr);
+}
+
+int gpe_mse_begin(gpe_engine* e) {
+    if (!e) return GPE_ERR_INVALID;
+    if (!e->mse_target || e->mse.n <= 0) FAIL(e, GPE_ERR_STATE, "mse step before bind_target");
+    int rc;
+    e->mse.x = e->main.x;
+    HIPCHK(e, hipMemsetAsync(e->dbl, 0, (S_COUNT + LS_COUNT + 4) * sizeof(double), e->stream));
+    HIPCHK(e, hipMemsetAsync(e->grad, 0, ((size_t)e->P + GT_COUNT) * sizeof(float), e->stream));
+    if ((rc = mlp_forward(e, e->mse, true))) return rc;
+    hipLaunchKernelGGL(k_seed_mse, dim3(head_grid(e, e->mse.n)), dim3(256), 0, e->stream, e->nd.n_out, e->mse_target,
+                       e->mse.O, e->mse.Ob, e->dsc() + 2, e->mse.n, e->mse.ld, e->ph.n_global);
+    HIPCHK(e, hipGetLastError());
+    if ((rc = mlp_backward(e, e->mse))) return rc;
+    hipLaunchKernelGGL(k_tail, dim3(1), dim3(1), 0, e->stream, e->grad + e->P, e->dsc());
+    HIPCHK(e, hipGetLastError());
+    e->phase = 3;
+    return GPE_OK;
+}
+
+static int mse_finish(gpe_engine* e, int do_update) {
+    if (e->phase != 3) FAIL(e, GPE_ERR_STATE, "mse update without mse begin");
+    // sums[S_DEN] must be non-zero for the (unused) Rayleigh quotient of the shared update kernel
+    hipLaunchKernelGGL(k_update, dim3(1), dim3(1024), 0, e->stream, e->P, e->theta, e->am, e->av, e->grad, e->sums(),
+                       e->lsums(), e->ph, e->oc, e->od, e->hist, e->cap, e->last, 0.0, do_update, 1);
+    HIPCHK(e, hipGetLastError());
+    if (do_update) e->packed_dirty = true;
+    e->phase = 0;
+    return GPE_OK;
+}
+
+int gpe_mse_update(gpe_engine* e) { return e ? mse_finish(e, 1) : GPE_ERR_INVALID; }
+
+int gpe_mse_step(gpe_engine* e, gpe_scalars* out) {
+    int rc;
+    if ((rc = gpe_mse_begin(e))) return rc;
+    if ((rc = mse_finish(e, 1))) return rc;
+    if (out) return gpe_read_scalars(e, out);
+    return GPE_OK;
+}
+
+int gpe_mse_loss_grad(gpe_engine* e, double* loss) {
+    int rc;
+    if ((rc = gpe_mse_begin(e))) return rc;
+    if ((rc = mse_finish(e, 0))) return rc;
+    gpe_scalars sc;
+    HIPCHK(e, hipMemcpyAsync(&sc, e->last, sizeof sc, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (loss) *loss = sc.loss;
     return GPE_OK;
 }
 
@@ -886,7 +953,7 @@ int gpe_residual(gpe_engine* e, gpe_scalars* out, float* d_psi, float* d_resid) 
                                   e->main.ld, e->nd.n_out);
     hipLaunchKernelGGL(k_tail, dim3(1), dim3(1), 0, e->stream, e->grad + e->P, e->dsc());
     hipLaunchKernelGGL(k_update, dim3(1), dim3(1024), 0, e->stream, e->P, e->theta, e->am, e->av, e->grad, e->sums(),
-                       e->lsums(), e->ph, e->oc, e->od, e->hist, e->cap, e->last, bc_count(e), 0);
+                       e->lsums(), e->ph, e->oc, e->od, e->hist, e->cap, e->last, bc_count(e), 0, 0);
     HIPCHK(e, hipGetLastError());
     e->phase = 0;
     HIPCHK(e, hipMemcpyAsync(out, e->last, sizeof *out, hipMemcpyDeviceToHost, e->stream));

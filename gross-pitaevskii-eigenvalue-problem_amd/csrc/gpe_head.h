@@ -197,6 +197,24 @@ __global__ __launch_bounds__(256) void k_seed_sym(Phys ph, const float* __restri
     }
 }
 
+// ---- pre-training: loss = mean((NN - target)^2)  (refine/harmonic_pinn_simulation.py:667-668) -----------------------------
+__global__ __launch_bounds__(256) void k_seed_mse(int n_out, const float* __restrict__ target, const float* __restrict__ O,
+                                                  float* __restrict__ Ob, double* __restrict__ acc, int64_t N, int64_t ld,
+                                                  double n_global) {
+    __shared__ double red[4];
+    double s = 0.0;
+    const float c = (float)(2.0 / (n_global * n_out));
+    for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < N; m += (int64_t)gridDim.x * 256) {
+        for (int o = 0; o < n_out; ++o) {
+            float e = O[(int64_t)o * ld + m] - target[m * n_out + o];
+            s += (double)(e * e);
+            Ob[(int64_t)o * ld + m] = c * e;
+        }
+    }
+    double t = block_sum_256(s, red);
+    if (threadIdx.x == 0) atomicAdd(acc, t);
+}
+
 // x -> [x ; -x]
 __global__ void k_make_sym_points(const float* __restrict__ x, float* __restrict__ xs, int64_t N, int dim) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;

@@ -321,6 +321,22 @@ class Engine:
         self._chk(self.lib.gpe_read_history(self._h, int(first_step), int(count), arr))
         return [a.as_dict() for a in arr]
 
+    # ---- pre-training on an analytic target (refine/harmonic_pinn_simulation.py:650-701) -----------------------------------
+    def bind_target(self, target):
+        t = None if target is None else self._to_dev(target, "target").reshape(-1, self.cfg.n_out)
+        self._keep["target"] = t
+        self._chk(self.lib.gpe_bind_target(self._h, C.c_void_p(t.data_ptr()) if t is not None else None))
+
+    def mse_step(self) -> dict:
+        sc = capi.gpe_scalars()
+        self._chk(self.lib.gpe_mse_step(self._h, C.byref(sc)))
+        return sc.as_dict()
+
+    def mse_loss_grad(self):
+        loss = C.c_double()
+        self._chk(self.lib.gpe_mse_loss_grad(self._h, C.byref(loss)))
+        return loss.value, self.get_grad()
+
     # ---- continuation knobs --------------------------------------------------------------------------------------------
     def set_gamma(self, g: float):
         self.cfg.gamma = float(g)

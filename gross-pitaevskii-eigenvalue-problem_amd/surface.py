@@ -192,6 +192,16 @@ class _PINNBase:
         eng.bind_points(x2)
         return eng.residual()
 
+    @staticmethod
+    def weighted_hermite_np(x, n):
+        """phi_n on the host in fp64 (target of the pre-training fit)."""
+        x = np.asarray(x, dtype=np.float64)
+        Hm1, Hc = np.zeros_like(x), np.ones_like(x)
+        for k in range(n):
+            Hm1, Hc = Hc, 2 * x * Hc - 2 * k * Hm1
+        norm = ((2.0 ** n) * float(math.factorial(n)) * math.sqrt(math.pi)) ** (-0.5)
+        return (norm * Hc * np.exp(-0.5 * x * x)).astype(np.float32)
+
     def get_complete_solution(self, x, perturbation, mode=None):
         mode = self.mode if mode is None else mode
         return self.weighted_hermite(x, mode) + perturbation
@@ -304,16 +314,61 @@ def _refine_advanced_initialization(m, mode):
         m._engine.set_params(m._flat)
 
 
+def _refine_pretrain(model, mode, X_train, epochs=5000, lr=1e-3, verbose=False):
+    """pretrain_on_analytical_solution (refine/harmonic_pinn_simulation.py:650-701): fit the network output to phi_mode(x).
+    Adam phase (epochs-500 iterations, plain Adam, no clipping) on the engine; then the reference's L-BFGS tail
+    (torch.optim.LBFGS(lr*0.1, max_iter=20), 500 outer iterations) driven host-side on the engine's loss/gradient."""
+    X = _as_np(X_train).astype(np.float32)
+    dev = _device()
+    X_dev = torch.as_tensor(X, device=dev)
+    eng = model._get_engine(lr=float(lr), sched=capi.SCHED_CONST, w_bc=0.0)
+    eng.reset_optimizer(float(lr))
+    eng.bind_points(X_dev)
+    target = model.weighted_hermite_np(X[:, 0], mode).reshape(-1, 1)
+    eng.bind_target(torch.as_tensor(target, device=dev))
+    loss = float("inf")
+    n_adam = max(epochs - 500, 0)
+    for epoch in range(n_adam):
+        loss = eng.mse_step()["loss"]
+        if verbose and epoch % 500 == 0:
+            print(f"  Pre-training epoch {epoch}, loss: {loss:.2e}")
+        if loss < 1e-12:
+            break
+    if loss >= 1e-12 and epochs > n_adam:
+        theta = torch.tensor(eng.get_params(), dtype=torch.float32, requires_grad=True)
+        opt = torch.optim.LBFGS([theta], lr=lr * 0.1, max_iter=20)
+
+        def closure():
+            opt.zero_grad()
+            eng.set_params(theta.detach().numpy())
+            l, g = eng.mse_loss_grad()
+            theta.grad = torch.from_numpy(g.copy())
+            return torch.tensor(l, dtype=torch.float32)
+
+        for epoch in range(n_adam, epochs):
+            loss = float(opt.step(closure))
+            if loss < 1e-12:
+                break
+        eng.set_params(theta.detach().numpy())
+    if verbose:
+        print(f"  Pre-training finished, final loss: {loss:.2e}")
+    eng.bind_target(None)
+    model._pull()
+    model.pretrain_loss = loss
+    return model
+
+
 def _refine_train(gamma_values, modes, p, X_train, lb, ub, layers, epochs, tol, perturb_const,
-                  potential_type="harmonic", lr=1e-5, verbose=True, pretrain=None, chunk=500):
+                  potential_type="harmonic", lr=1e-5, verbose=True, pretrain="reference", chunk=500):
     """train_gpe_model of refine/harmonic_pinn_simulation.py:220-430 (PL-PINN, gamma continuation).
 
     Differences from the reference, all deliberate:
       Q5  the reference "restores the best model" from a shallow state_dict copy, i.e. it keeps the LAST weights; so do we.
       Q6  normal_const is taken at the first epoch of the first gamma of each mode (the reference only defines it when that
           gamma is 0 and raises NameError otherwise).
-      pretraining (:300-303, row f2 of SURVEY 8) is done by `pretrain` if given (callable(model, mode, X_train)); otherwise
-      the gamma==0 start uses advanced_initialization like any other start.
+      pretraining (:300-303): `pretrain="reference"` (default) runs pretrain_on_analytical_solution(epochs=2000, lr=1e-3) when
+      the first gamma is 0, as the reference does; `pretrain=None` skips it (advanced_initialization instead); a callable
+      (model, mode, X_train) -> model replaces it.
     Epoch bodies are enqueued `chunk` at a time with no host synchronisation; early stopping (:389-400) is evaluated on the
     device after every update, so the stop epoch is exact.
     """
@@ -341,7 +396,10 @@ def _refine_train(gamma_values, modes, p, X_train, lb, ub, layers, epochs, tol, 
             if prev_model is not None:
                 model.load_state_dict(prev_model.state_dict())
             elif gamma == 0.0 and pretrain is not None:
-                model = pretrain(model, mode, X_train)
+                if pretrain == "reference":
+                    model = _refine_pretrain(model, mode, X_train, epochs=2000, lr=1e-3, verbose=verbose)   # :302-303
+                else:
+                    model = pretrain(model, mode, X_train)
             else:
                 model.apply(lambda m: _refine_advanced_initialization(m, mode))
             if normal_const is None:                                   # :333-335
@@ -484,6 +542,7 @@ def _nb_density(model, X_test, mode=None):
 
 refine = types.SimpleNamespace(GrossPitaevskiiPINN=_RefinePINN, train_gpe_model=_refine_train,
                                advanced_initialization=_refine_advanced_initialization,
+                               pretrain_on_analytical_solution=_refine_pretrain,
                                normalized_wavefunction=_refine_wavefunction)
 notebook = types.SimpleNamespace(GrossPitaevskiiPINN=_NotebookPINN, train_gpe_model=_nb_train,
                                  advanced_initialization=_nb_advanced_initialization, density=_nb_density)

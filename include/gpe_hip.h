@@ -170,6 +170,17 @@ int gpe_synchronize(gpe_engine* e);
 /* early-stop state: *stopped = 1 once a stop condition fired; *stop_step = the optimiser step that fired it (1-based) */
 int gpe_stop_state(gpe_engine* e, int* stopped, int64_t* stop_step);
 
+/* ---- pre-training on an analytic target: pretrain_on_analytical_solution (refine/...:650-701) ------------------------
+ * loss = mean((NN(x) - target)^2) on the bound points; d_target [n_local,out].  gpe_mse_step: one plain Adam step (no
+ * clipping, no scheduler, refine/...:663-670); gpe_mse_loss_grad: loss + gradient without update (the reference's L-BFGS
+ * tail, refine/...:672-687, runs host-side on these; read the gradient with gpe_get_grad).  Single-rank entry points; the
+ * phases gpe_mse_begin / gpe_mse_update bracket an all-reduce of the gradient exchange buffer when world_size > 1. */
+int gpe_bind_target(gpe_engine* e, const float* d_target);
+int gpe_mse_begin(gpe_engine* e);                    /* forward, seeds, reverse -> gradient exchange buffer (tail: sum of squares) */
+int gpe_mse_update(gpe_engine* e);                   /* Adam on the exchanged gradient */
+int gpe_mse_step(gpe_engine* e, gpe_scalars* out);   /* begin + update + synchronise; out->loss = the MSE */
+int gpe_mse_loss_grad(gpe_engine* e, double* loss);
+
 /* ---- continuation knobs: the gamma / perturbation loop of refine/...:289-340 -------------------------- */
 int gpe_set_gamma(gpe_engine* e, float gamma);
 int gpe_set_power(gpe_engine* e, int p);

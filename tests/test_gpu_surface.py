@@ -127,3 +127,41 @@ def test_gamma_continuation_against_independent_solver():
     for g in (0.0, 1.0, 2.0):
         assert abs(models[g].last_mu - exact[g]) < 2e-3, (g, models[g].last_mu, exact[g])
     assert abs(models[0.0].last_mu - 1.0) < 5e-5
+
+
+def test_pretrain_on_analytical_solution():
+    """refine/harmonic_pinn_simulation.py:650-701 on the engine: Adam phase on the device, L-BFGS tail host-side on the C ABI's
+    loss/gradient.  The fit must reach the accuracy the reference's own pre-training reaches (loss ~1e-6 and below)."""
+    torch.manual_seed(0)
+    X = np.linspace(-10, 10, 1000).reshape(-1, 1)
+    for mode in (0, 2):
+        model = refine.GrossPitaevskiiPINN([1, 64, 64, 64, 1], mode=mode, gamma=0.0)
+        model = refine.pretrain_on_analytical_solution(model, mode, X, epochs=1200, lr=1e-3)
+        out = model.forward(torch.as_tensor(X.astype(np.float32), device="cuda")).cpu().numpy()[:, 0]
+        tgt = model.weighted_hermite_np(X[:, 0], mode)
+        assert model.pretrain_loss < 2e-5, model.pretrain_loss
+        assert np.abs(out - tgt).max() < 3e-2
+        model.close()
+
+
+def test_mse_gradient_matches_oracle():
+    from oracle import gpe_oracle as go
+    rng = np.random.default_rng(5)
+    layers = [1, 32, 32, 1]
+    x = np.linspace(-3, 3, 200).reshape(-1, 1)
+    flat = (rng.normal(0, 0.4, go.param_count(layers))).astype(np.float32)
+    target = np.exp(-x ** 2)
+    eng = gpe_pinn.Engine(gpe_pinn.GPEConfig(layers=layers, w_bc=0.0))
+    eng.set_params(flat)
+    eng.bind_points(torch.as_tensor(x.astype(np.float32), device="cuda"))
+    eng.bind_target(torch.as_tensor(target.astype(np.float32), device="cuda"))
+    loss, grad = eng.mse_loss_grad()
+    params = go.unflatten(flat.astype(np.float64), layers)
+    o, cache = go.mlp_forward(params, x, 0, value_only=True)
+    e = o[0] - target
+    ograd = go.mlp_backward(params, cache, (2.0 / e.size * e)[None], value_only=True)
+    assert abs(loss - float((e * e).mean())) < 1e-5 * float((e * e).mean())
+    assert H.rel_err(grad, ograd) < 2e-5
+    sc = eng.mse_step()                                   # plain Adam: every weight moves by ~lr on the first step
+    d = np.abs(eng.get_params() - flat)
+    assert 0.5e-3 < np.median(d) < 1.5e-3 and abs(sc["loss"] - loss) < 1e-6
