@@ -21,6 +21,8 @@ ACT_TANH, ACT_TANH_PLUS1 = 0, 1
 POT_HARMONIC, POT_GAUSSIAN, POT_PERIODIC, POT_PRECOMPUTED, POT_NONE = 0, 1, 2, 3, 4
 SCHED_CONST, SCHED_COSINE_LOSS, SCHED_PLATEAU = 0, 1, 2
 PATH_AUTO, PATH_GENERIC, PATH_FUSED = 0, 1, 2
+BASE_HERMITE, BASE_BOX, BASE_PRECOMPUTED = 0, 1, 2
+ENV_NONE, ENV_SIN = 0, 1
 
 
 class gpe_config(C.Structure):
@@ -38,6 +40,7 @@ class gpe_config(C.Structure):
         ("factor", C.c_float), ("patience", C.c_int32), ("min_lr", C.c_float), ("threshold", C.c_float),
         ("path", C.c_int32), ("world_size", C.c_int32), ("history_capacity", C.c_int32),
         ("stop_tol", C.c_float), ("stop_patience", C.c_int32),
+        ("base_kind", C.c_int32), ("envelope", C.c_int32), ("box_L", C.c_float), ("env_L", C.c_float),
     ]
 
 
@@ -74,6 +77,7 @@ SYMBOLS = {
     "gpe_bind_points": (_int, [_vp, _vp, _i64, _vp]),
     "gpe_bind_boundary": (_int, [_vp, _vp, _i64, _vp]),
     "gpe_bind_orth": (_int, [_vp, _int, _vp]),
+    "gpe_bind_base": (_int, [_vp, _vp, _vp, _vp]),
     "gpe_forward": (_int, [_vp, _vp, _i64, _vp]),
     "gpe_forward_jets": (_int, [_vp, _vp, _i64, _vp]),
     "gpe_residual": (_int, [_vp, _P(gpe_scalars), _vp, _vp]),

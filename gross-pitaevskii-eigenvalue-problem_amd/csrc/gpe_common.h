@@ -27,7 +27,8 @@ struct Phys {
     float omega_rot;
     float gamma;
     int p, abs_power;
-    int base_mode, base_deriv;
+    int base_mode, base_deriv, base_kind, envelope;
+    float box_L, env_L;
     float perturb_scale, bc_nn_scale;
     float w_pde, w_bc, w_norm, w_sym, w_orth, sym_sign;
     float dx;
@@ -139,6 +140,27 @@ GPE_DEV void hermite_base(float x, int n, int deriv_mode, float norm, float& phi
     phi = norm * (H * w);
     phi1 = norm * w * (H1 - x * H);
     phi2 = norm * w * (H2 - 2.f * x * H1 + (x * x - 1.f) * H);
+}
+
+// base phi_n and its first two derivatives at a 1D point (kinds HERMITE / BOX)
+GPE_DEV void base_at(const Phys& ph, float x, float hermite_norm, float& phi, float& phi1, float& phi2) {
+    if (ph.base_kind == GPE_BASE_BOX) {               // refine/box_pinn_simulation.py:99-117,141-180
+        const float k = (float)(ph.base_mode + 1) * 3.14159265358979323846f / ph.box_L;
+        const float a = sqrtf(2.0f / ph.box_L);
+        float sn, cs;
+        sincosf(k * x, &sn, &cs);
+        phi = a * sn; phi1 = a * k * cs; phi2 = -a * k * k * sn;
+    } else {
+        hermite_base(x, ph.base_mode, ph.base_deriv, hermite_norm, phi, phi1, phi2);
+    }
+}
+
+// hard boundary factor f(x) = sin(pi x / L) and derivatives (refine/box_pinn_simulation.py:127-130)
+GPE_DEV void envelope_at(const Phys& ph, float x, float& f, float& f1, float& f2) {
+    const float k = 3.14159265358979323846f / ph.env_L;
+    float sn, cs;
+    sincosf(k * x, &sn, &cs);
+    f = sn; f1 = k * cs; f2 = -k * k * sn;
 }
 
 GPE_DEV float potential_at(const Phys& ph, const float* xv, const float* Vpre, int64_t m) {

@@ -199,7 +199,7 @@ struct gpe_engine {
     std::vector<int> ev_kind;             // 0 forward, 1 reverse
     size_t ev_used = 0;
     const float** orth_dev = nullptr;
-    const float* orth_host[GPE_MAX_ORTH] = {nullptr, nullptr, nullptr, nullptr};
+    const float* orth_host[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [4..6]: precomputed base
     Batch main, bc, sym, aux, mse;
     const float* bc_target = nullptr;
     const float* mse_target = nullptr;
@@ -429,13 +429,14 @@ static void fill_phys(gpe_engine* e) {
     for (int k = 0; k < 3; ++k) p.omega[k] = c.omega[k];
     p.pot_a = c.pot_a; p.pot_v0 = c.pot_v0; p.pot_k = c.pot_k; p.omega_rot = c.omega_rot;
     p.gamma = c.gamma; p.p = c.p; p.abs_power = c.abs_power; p.base_mode = c.base_mode; p.base_deriv = c.base_deriv;
+    p.base_kind = c.base_kind; p.envelope = c.envelope; p.box_L = c.box_L > 0.f ? c.box_L : 1.f; p.env_L = c.env_L > 0.f ? c.env_L : 1.f;
     p.perturb_scale = c.perturb_scale; p.bc_nn_scale = c.bc_nn_scale;
     p.w_pde = c.w_pde; p.w_bc = c.w_bc; p.w_norm = c.w_norm; p.w_sym = c.w_sym; p.w_orth = c.w_orth;
     p.sym_sign = c.sym_sign; p.dx = c.dx;
     p.n_global = (double)(c.n_global > 0 ? c.n_global : (e->main.n > 0 ? e->main.n : 1));
     p.inv_world = 1.0f / (float)(c.world_size > 0 ? c.world_size : 1);
     int no = 0;
-    for (int j = 0; j < GPE_MAX_ORTH; ++j) if (e->orth_host[j]) no = j + 1;
+    for (int j = 0; j < GPE_MAX_ORTH; ++j) if (e->orth_host[j]) no = j + 1;      // [4..6] are the precomputed base
     p.n_orth = no;
     if (c.base_mode >= 0) {
         double f = 1.0;
@@ -502,6 +503,9 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
     if (c.base_mode >= 0 && (dim != 1 || no != 1)) CFAIL("Hermite base needs dim=1, out=1");
     if (c.p < 1 || c.p > 32) CFAIL("power p must be in [1,32]");
     if (c.omega_rot != 0.f && (!c.complex_psi || dim < 2)) CFAIL("rotation needs complex psi and dim>=2");
+    if (c.base_kind < 0 || c.base_kind > GPE_BASE_PRECOMPUTED) CFAIL("Unknown base kind: %d", c.base_kind);
+    if (c.envelope < 0 || c.envelope > GPE_ENV_SIN) CFAIL("Unknown envelope: %d", c.envelope);
+    if (c.envelope != GPE_ENV_NONE && (dim != 1 || no != 1)) CFAIL("the boundary factor needs dim=1, out=1");
     for (int i = 1; i < c.n_layers - 1; ++i)
         if (c.layers[i] < 1 || c.layers[i] > 1024) CFAIL("hidden width %d out of range", c.layers[i]);
     NetDesc& nd = e->nd;
@@ -544,7 +548,7 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
               alloc((void**)&e->av, (size_t)e->P * 4) && alloc((void**)&e->grad, ((size_t)e->P + GT_COUNT) * 4) &&
               alloc((void**)&e->dbl, (S_COUNT + LS_COUNT + 4) * sizeof(double)) && alloc((void**)&e->od, sizeof(OptDev)) &&
               alloc((void**)&e->hist, (size_t)e->cap * sizeof(gpe_scalars)) && alloc((void**)&e->last, sizeof(gpe_scalars)) &&
-              alloc((void**)&e->orth_dev, GPE_MAX_ORTH * sizeof(float*));
+              alloc((void**)&e->orth_dev, 8 * sizeof(float*));
     if (ok && e->path == GPE_PATH_FUSED) {
         e->nslab = e->num_cu * 2;
         ok = alloc((void**)&e->Wpk, (size_t)(Lh - 1) * H * H * 4) && alloc((void**)&e->WpkT, (size_t)(Lh - 1) * H * H * 4) &&
@@ -701,6 +705,14 @@ int gpe_bind_orth(gpe_engine* e, int k, const float* d_psi) {
     return GPE_OK;
 }
 
+int gpe_bind_base(gpe_engine* e, const float* d_phi, const float* d_phi1, const float* d_phi2) {
+    if (!e) return GPE_ERR_INVALID;
+    e->orth_host[4] = d_phi; e->orth_host[5] = d_phi1; e->orth_host[6] = d_phi2;
+    HIPCHK(e, hipMemcpyAsync((void*)e->orth_dev, e->orth_host, sizeof e->orth_host, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return GPE_OK;
+}
+
 // ---- forward-only ----------------------------------------------------------------------------------
 static int aux_forward(gpe_engine* e, const float* d_x, int64_t n, int C) {
     int rc = setup_batch(e, e->aux, d_x, n, C, true, nullptr);
@@ -712,7 +724,7 @@ int gpe_forward(gpe_engine* e, const float* d_x, int64_t n, float* d_out) {
     if (!e || !d_x || !d_out || n <= 0) return GPE_ERR_INVALID;
     int rc = aux_forward(e, d_x, n, 1);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_copy_values, dim3(cdiv(n, 256)), dim3(256), 0, e->stream, e->aux.O, d_out, n, e->aux.ld, e->nd.n_out);
+    hipLaunchKernelGGL(k_copy_values, dim3(cdiv(n, 256)), dim3(256), 0, e->stream, e->ph, d_x, e->aux.O, d_out, n, e->aux.ld, e->nd.n_out);
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipStreamSynchronize(e->stream));
     return GPE_OK;
@@ -731,6 +743,8 @@ int gpe_forward_jets(gpe_engine* e, const float* d_x, int64_t n, float* d_jets) 
 
 int gpe_eval_density(gpe_engine* e, const float* d_x, int64_t n, float dx, int abs_flag, float* d_u, float* d_dens) {
     if (!e || !d_x || n <= 0) return GPE_ERR_INVALID;
+    if (e->cfg.base_mode >= 0 && e->cfg.base_kind == GPE_BASE_PRECOMPUTED)
+        FAIL(e, GPE_ERR_INVALID, "eval_density needs an analytic base (the precomputed base exists on the bound points only)");
     int rc = aux_forward(e, d_x, n, 1);
     if (rc) return rc;
     double* acc = e->dsc() + 1;
@@ -768,6 +782,8 @@ static int launch_seed_pde(gpe_engine* e, float* d_resid, int want_seeds) {
 int gpe_step_begin(gpe_engine* e) {
     if (!e) return GPE_ERR_INVALID;
     if (e->main.n <= 0) FAIL(e, GPE_ERR_STATE, "step before bind_points");
+    if (e->cfg.base_mode >= 0 && e->cfg.base_kind == GPE_BASE_PRECOMPUTED && !e->orth_host[4])
+        FAIL(e, GPE_ERR_STATE, "precomputed base requested but gpe_bind_base was not called");
     int rc;
     HIPCHK(e, hipMemsetAsync(e->dbl, 0, (S_COUNT + LS_COUNT + 4) * sizeof(double), e->stream));
     HIPCHK(e, hipMemsetAsync(e->grad, 0, ((size_t)e->P + GT_COUNT) * sizeof(float), e->stream));
@@ -843,8 +859,8 @@ int gpe_mse_begin(gpe_engine* e) {
     HIPCHK(e, hipMemsetAsync(e->dbl, 0, (S_COUNT + LS_COUNT + 4) * sizeof(double), e->stream));
     HIPCHK(e, hipMemsetAsync(e->grad, 0, ((size_t)e->P + GT_COUNT) * sizeof(float), e->stream));
     if ((rc = mlp_forward(e, e->mse, true))) return rc;
-    hipLaunchKernelGGL(k_seed_mse, dim3(head_grid(e, e->mse.n)), dim3(256), 0, e->stream, e->nd.n_out, e->mse_target,
-                       e->mse.O, e->mse.Ob, e->dsc() + 2, e->mse.n, e->mse.ld, e->ph.n_global);
+    hipLaunchKernelGGL(k_seed_mse, dim3(head_grid(e, e->mse.n)), dim3(256), 0, e->stream, e->ph, e->mse.x, e->mse_target,
+                       e->mse.O, e->mse.Ob, e->dsc() + 2, e->mse.n, e->mse.ld);
     HIPCHK(e, hipGetLastError());
     if ((rc = mlp_backward(e, e->mse))) return rc;
     hipLaunchKernelGGL(k_tail, dim3(1), dim3(1), 0, e->stream, e->grad + e->P, e->dsc());

@@ -8,15 +8,27 @@
 #include "gpe_common.h"
 
 // u-jets (value, first, second derivatives) of component o at point m from NN output jets.
+// bptr: device array of pointers; [0..3] orthogonality modes, [4..6] precomputed base phi, phi', phi''.
 template <int C>
 GPE_DEV void load_u_jets(const Phys& ph, const float* __restrict__ O, int64_t ld, int64_t m, int o,
-                         const float* xv, float base_norm, float* U /*[C]*/) {
+                         const float* xv, float base_norm, const float* const* __restrict__ bptr, float* U /*[C]*/) {
 #pragma unroll
     for (int c = 0; c < C; ++c) U[c] = ph.perturb_scale * O[((int64_t)c * ph.n_out + o) * ld + m];
-    if (ph.base_mode >= 0 && C == 3) {
-        float phi, p1, p2;
-        hermite_base(xv[0], ph.base_mode, ph.base_deriv, base_norm, phi, p1, p2);
-        U[0] += phi; U[1] += p1; U[2] += p2;
+    if constexpr (C == 3) {
+        if (ph.envelope == GPE_ENV_SIN) {              // psi = o f : product rule on the jets
+            float f, f1, f2;
+            envelope_at(ph, xv[0], f, f1, f2);
+            const float o0 = U[0], o1 = U[1], o2 = U[2];
+            U[0] = o0 * f;
+            U[1] = fmaf(o1, f, o0 * f1);
+            U[2] = fmaf(o2, f, fmaf(2.0f * o1, f1, o0 * f2));
+        }
+        if (ph.base_mode >= 0) {
+            float phi, p1, p2;
+            if (ph.base_kind == GPE_BASE_PRECOMPUTED) { phi = bptr[4][m]; p1 = bptr[5][m]; p2 = bptr[6][m]; }
+            else base_at(ph, xv[0], base_norm, phi, p1, p2);
+            U[0] += phi; U[1] += p1; U[2] += p2;
+        }
     }
 }
 
@@ -36,7 +48,7 @@ __global__ __launch_bounds__(256) void k_head_pde(Phys ph, float base_norm, cons
         for (int k = 0; k < ph.dim; ++k) xv[k] = x[m * ph.dim + k];
         float V = potential_at(ph, xv, Vpre, m);
         float U[2][C];
-        for (int o = 0; o < ph.n_out; ++o) load_u_jets<C>(ph, O, ld, m, o, xv, base_norm, U[o]);
+        for (int o = 0; o < ph.n_out; ++o) load_u_jets<C>(ph, O, ld, m, o, xv, base_norm, orth, U[o]);
         float Hu[2] = {0.f, 0.f};
         if (!ph.complex_psi) {
             float u = U[0][0], lap = 0.f;
@@ -133,6 +145,16 @@ __global__ __launch_bounds__(256) void k_seed_pde(Phys ph, const float* __restri
                     if (o == 1) { Ub[2] += -Om * xv[0] * rb[0]; Ub[1] += Om * xv[1] * rb[0]; }
                     else        { Ub[2] += Om * xv[0] * rb[1];  Ub[1] += -Om * xv[1] * rb[1]; }
                 }
+                if constexpr (C == 3) {
+                    if (ph.envelope == GPE_ENV_SIN) {      // adjoint of psi = o f
+                        float f, f1, f2;
+                        envelope_at(ph, xv[0], f, f1, f2);
+                        const float u0 = Ub[0], u1 = Ub[1], u2 = Ub[2];
+                        Ub[0] = fmaf(f, u0, fmaf(f1, u1, f2 * u2));
+                        Ub[1] = fmaf(f, u1, 2.0f * f1 * u2);
+                        Ub[2] = f * u2;
+                    }
+                }
 #pragma unroll
                 for (int c = 0; c < C; ++c) Ob[((int64_t)c * ph.n_out + o) * ld + m] = sc * Ub[c];
             }
@@ -153,15 +175,17 @@ __global__ __launch_bounds__(256) void k_head_seed_bc(Phys ph, float base_norm, 
     if (m < nb) {
         float cnt = (float)(nb * ph.n_out);
         for (int o = 0; o < ph.n_out; ++o) {
-            float e = ph.bc_nn_scale * O[(int64_t)o * ld + m];
-            if (ph.base_mode >= 0 && o == 0) {
+            float fenv = 1.0f;
+            if (ph.envelope == GPE_ENV_SIN) { float f1, f2; envelope_at(ph, xb[m * ph.dim], fenv, f1, f2); }
+            float e = ph.bc_nn_scale * fenv * O[(int64_t)o * ld + m];
+            if (ph.base_mode >= 0 && o == 0 && ph.base_kind != GPE_BASE_PRECOMPUTED) {
                 float phi, p1, p2;
-                hermite_base(xb[m * ph.dim], ph.base_mode, ph.base_deriv, base_norm, phi, p1, p2);
+                base_at(ph, xb[m * ph.dim], base_norm, phi, p1, p2);
                 e += phi;
             }
             if (target) e -= target[m * ph.n_out + o];
             se += (double)(e * e);
-            Ob[(int64_t)o * ld + m] = ph.w_bc * 2.0f / cnt * e * ph.bc_nn_scale * ph.inv_world;
+            Ob[(int64_t)o * ld + m] = ph.w_bc * 2.0f / cnt * e * ph.bc_nn_scale * fenv * ph.inv_world;
         }
     }
     double t = block_sum_256(se, red);
@@ -198,17 +222,20 @@ __global__ __launch_bounds__(256) void k_seed_sym(Phys ph, const float* __restri
 }
 
 // ---- pre-training: loss = mean((NN - target)^2)  (refine/harmonic_pinn_simulation.py:667-668) -----------------------------
-__global__ __launch_bounds__(256) void k_seed_mse(int n_out, const float* __restrict__ target, const float* __restrict__ O,
-                                                  float* __restrict__ Ob, double* __restrict__ acc, int64_t N, int64_t ld,
-                                                  double n_global) {
+__global__ __launch_bounds__(256) void k_seed_mse(Phys ph, const float* __restrict__ x, const float* __restrict__ target,
+                                                  const float* __restrict__ O, float* __restrict__ Ob,
+                                                  double* __restrict__ acc, int64_t N, int64_t ld) {
     __shared__ double red[4];
     double s = 0.0;
-    const float c = (float)(2.0 / (n_global * n_out));
+    const int n_out = ph.n_out;
+    const float c = (float)(2.0 / (ph.n_global * n_out));
     for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < N; m += (int64_t)gridDim.x * 256) {
+        float fenv = 1.0f;
+        if (ph.envelope == GPE_ENV_SIN) { float f1, f2; envelope_at(ph, x[m * ph.dim], fenv, f1, f2); }
         for (int o = 0; o < n_out; ++o) {
-            float e = O[(int64_t)o * ld + m] - target[m * n_out + o];
+            float e = fenv * O[(int64_t)o * ld + m] - target[m * n_out + o];       // model.forward includes the factor
             s += (double)(e * e);
-            Ob[(int64_t)o * ld + m] = c * e;
+            Ob[(int64_t)o * ld + m] = c * e * fenv;
         }
     }
     double t = block_sum_256(s, red);
@@ -222,9 +249,14 @@ __global__ void k_make_sym_points(const float* __restrict__ x, float* __restrict
 }
 
 // out [n,out] row-major from O[0][o][m]
-__global__ void k_copy_values(const float* __restrict__ O, float* __restrict__ out, int64_t N, int64_t ld, int n_out) {
+__global__ void k_copy_values(Phys ph, const float* __restrict__ x, const float* __restrict__ O, float* __restrict__ out,
+                              int64_t N, int64_t ld, int n_out) {
     int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (m < N) for (int o = 0; o < n_out; ++o) out[m * n_out + o] = O[(int64_t)o * ld + m];
+    if (m < N) {
+        float fenv = 1.0f;
+        if (ph.envelope == GPE_ENV_SIN) { float f1, f2; envelope_at(ph, x[m * ph.dim], fenv, f1, f2); }
+        for (int o = 0; o < n_out; ++o) out[m * n_out + o] = fenv * O[(int64_t)o * ld + m];
+    }
 }
 // jets [C][n][out] from O [C][out][ld]
 __global__ void k_copy_jets(const float* __restrict__ O, float* __restrict__ jets, int64_t N, int64_t ld, int n_out, int C) {
@@ -247,9 +279,10 @@ __global__ __launch_bounds__(256) void k_eval_u(Phys ph, float base_norm, const 
     if (m < N) {
         for (int o = 0; o < ph.n_out; ++o) {
             float v = ph.perturb_scale * O[(int64_t)o * ld + m];
+            if (ph.envelope == GPE_ENV_SIN) { float f, f1, f2; envelope_at(ph, x[m * ph.dim], f, f1, f2); v *= f; }
             if (ph.base_mode >= 0 && o == 0) {
                 float phi, p1, p2;
-                hermite_base(x[m * ph.dim], ph.base_mode, ph.base_deriv, base_norm, phi, p1, p2);
+                base_at(ph, x[m * ph.dim], base_norm, phi, p1, p2);
                 v += phi;
             }
             u[(int64_t)o * ld + m] = v;

@@ -69,6 +69,10 @@ class GPEConfig:
     history_capacity: int = 0
     stop_tol: float = 0.0
     stop_patience: int = 0
+    base_kind: int = capi.BASE_HERMITE
+    envelope: int = capi.ENV_NONE
+    box_L: float = 1.0
+    env_L: float = 1.0
 
     def to_c(self) -> capi.gpe_config:
         c = capi.gpe_config()
@@ -83,14 +87,14 @@ class GPEConfig:
         for i in range(3):
             c.omega[i] = float(om[i])
         for name in ("activation", "potential", "p", "base_mode", "base_deriv", "sched", "patience", "path",
-                     "world_size", "history_capacity", "n_global", "stop_patience"):
+                     "world_size", "history_capacity", "n_global", "stop_patience", "base_kind", "envelope"):
             setattr(c, name, int(getattr(self, name)))
         c.complex_psi = int(bool(self.complex_psi))
         c.abs_power = int(bool(self.abs_power))
         for name in ("kinetic_coeff", "pot_scale", "pot_a", "pot_v0", "pot_k", "omega_rot", "gamma", "perturb_scale",
                      "bc_nn_scale", "w_pde", "w_bc", "w_norm", "w_sym", "w_orth", "sym_sign", "dx", "lr", "beta1",
                      "beta2", "eps", "clip_norm", "T_0", "T_mult", "eta_min", "factor", "min_lr", "threshold",
-                     "stop_tol"):
+                     "stop_tol", "box_L", "env_L"):
             setattr(c, name, float(getattr(self, name)))
         return c
 
@@ -228,6 +232,12 @@ class Engine:
         self._keep["xb"], self._keep["tg"] = xb, tg
         self._chk(self.lib.gpe_bind_boundary(self._h, C.c_void_p(xb.data_ptr()), xb.shape[0],
                                              C.c_void_p(tg.data_ptr()) if tg is not None else None))
+
+    def bind_base(self, phi, phi1, phi2):
+        """GPE_BASE_PRECOMPUTED: base function and its first two derivatives on the bound points."""
+        ts = [self._to_dev(a, "base").reshape(-1) for a in (phi, phi1, phi2)]
+        self._keep["base"] = ts
+        self._chk(self.lib.gpe_bind_base(self._h, *[C.c_void_p(t.data_ptr()) for t in ts]))
 
     def bind_orth(self, k: int, psi_k):
         t = None if psi_k is None else self._to_dev(psi_k, "psi_k").reshape(-1)

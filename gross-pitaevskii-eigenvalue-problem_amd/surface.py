@@ -27,7 +27,7 @@ import torch
 from . import _capi as capi
 from .engine import Engine, GPEConfig
 
-_POT = {"harmonic": capi.POT_HARMONIC, "gaussian": capi.POT_GAUSSIAN, "periodic": capi.POT_PERIODIC}
+_POT = {"harmonic": capi.POT_HARMONIC, "gaussian": capi.POT_GAUSSIAN, "periodic": capi.POT_PERIODIC, "box": capi.POT_NONE}
 
 
 def _device():
@@ -150,8 +150,12 @@ class _PINNBase:
                   base_mode=(self.mode if getattr(self, "use_perturbation", True) else -1), base_deriv=f.base_deriv,
                   gamma=float(self.gamma), perturb_scale=float(self.perturb_scale), w_sym=f.w_sym,
                   sym_sign=(-1.0 if self.mode % 2 == 1 else 1.0))
+        kw.update(self._extra_config())
         kw.update(over)
         return GPEConfig(**kw)
+
+    def _extra_config(self) -> dict:
+        return {}
 
     def _get_engine(self, **over) -> Engine:
         key = tuple(sorted(over.items()))
@@ -269,6 +273,36 @@ class _RefinePINN(_PINNBase):
                 torch.tensor(sc["mu"], dtype=torch.float32, device=dev))
 
 
+class _BoxPINN(_RefinePINN):
+    """refine/box_pinn_simulation.py:52-265: particle in a box [0, L]; forward = network(x) * sin(pi x) (hard boundary
+    factor, :119-130), base sqrt(2/L) sin((n+1) pi x / L) (:99-117), V = 0."""
+
+    def __init__(self, layers, hbar=1.0, m=1.0, mode=0, gamma=1.0, L=1.0, use_residual=True, use_perturbation=True):
+        super().__init__(layers, hbar, m, mode, gamma, use_perturbation)
+        self.L = L
+        self.use_residual = use_residual
+
+    def _extra_config(self):
+        return dict(base_kind=capi.BASE_BOX, box_L=float(self.L), envelope=capi.ENV_SIN, env_L=1.0, potential=capi.POT_NONE)
+
+    def box_eigenfunction(self, x, n):
+        return math.sqrt(2.0 / self.L) * torch.sin((n + 1) * math.pi * x / self.L)
+
+    def weighted_hermite(self, x, n):            # the base of this flavour
+        return self.box_eigenfunction(x, n)
+
+    def weighted_hermite_np(self, x, n):
+        return (math.sqrt(2.0 / self.L) * np.sin((n + 1) * math.pi * np.asarray(x, np.float64) / self.L)).astype(np.float32)
+
+    def compute_potential(self, x, potential_type="box", **kwargs):
+        if potential_type != "box":
+            raise ValueError(f"Unknown potential type: {potential_type}")
+        return torch.zeros_like(x)
+
+    def pde_loss(self, inputs, predictions, gamma, p, potential_type="box", precomputed_potential=None):
+        return super().pde_loss(inputs, predictions, gamma, p, potential_type, precomputed_potential)
+
+
 class _NotebookPINN(_PINNBase):
     """Gross_Pitaevskii_1D_power_Test.ipynb c6."""
     _flavor = _NOTEBOOK
@@ -359,7 +393,7 @@ def _refine_pretrain(model, mode, X_train, epochs=5000, lr=1e-3, verbose=False):
 
 
 def _refine_train(gamma_values, modes, p, X_train, lb, ub, layers, epochs, tol, perturb_const,
-                  potential_type="harmonic", lr=1e-5, verbose=True, pretrain="reference", chunk=500):
+                  potential_type="harmonic", lr=1e-5, verbose=True, pretrain="reference", chunk=500, _cls=None, **model_kw):
     """train_gpe_model of refine/harmonic_pinn_simulation.py:220-430 (PL-PINN, gamma continuation).
 
     Differences from the reference, all deliberate:
@@ -392,7 +426,7 @@ def _refine_train(gamma_values, modes, p, X_train, lb, ub, layers, epochs, tol, 
         for gamma in gamma_values:
             if verbose:
                 print(f"\nTraining for γ = {gamma:.2f}, mode = {mode}, nonlinearity p = {p}")
-            model = _RefinePINN(layers, mode=mode, gamma=gamma)
+            model = (_cls or _RefinePINN)(layers, mode=mode, gamma=gamma, **model_kw)
             if prev_model is not None:
                 model.load_state_dict(prev_model.state_dict())
             elif gamma == 0.0 and pretrain is not None:
@@ -540,6 +574,18 @@ def _nb_density(model, X_test, mode=None):
     return dens.cpu().numpy()
 
 
+def _box_train(gamma_values, modes, p, X_train, lb, ub, layers, epochs, tol, perturb_const, potential_type="box", lr=1e-5,
+               verbose=True, L=1.0, **kw):
+    """train_gpe_model of refine/box_pinn_simulation.py:267-470 (same loop as the harmonic one, box model class)."""
+    if potential_type != "box":
+        raise ValueError(f"Unknown potential type: {potential_type}")
+    return _refine_train(gamma_values, modes, p, X_train, lb, ub, layers, epochs, tol, perturb_const, "box", lr, verbose,
+                         _cls=_BoxPINN, L=L, **kw)
+
+
+box = types.SimpleNamespace(GrossPitaevskiiPINN=_BoxPINN, train_gpe_model=_box_train,
+                            advanced_initialization=_refine_advanced_initialization,
+                            pretrain_on_analytical_solution=_refine_pretrain)
 refine = types.SimpleNamespace(GrossPitaevskiiPINN=_RefinePINN, train_gpe_model=_refine_train,
                                advanced_initialization=_refine_advanced_initialization,
                                pretrain_on_analytical_solution=_refine_pretrain,

@@ -50,6 +50,13 @@ enum { GPE_POT_HARMONIC = 0, GPE_POT_GAUSSIAN = 1, GPE_POT_PERIODIC = 2,   /* nb
        GPE_POT_PRECOMPUTED = 3, GPE_POT_NONE = 4 };
 enum { GPE_SCHED_CONST = 0, GPE_SCHED_COSINE_LOSS = 1, GPE_SCHED_PLATEAU = 2 }; /* refine/...:312-314,361 (quirk Q4) ; nb c10:L76-78,L103 */
 enum { GPE_PATH_AUTO = 0, GPE_PATH_GENERIC = 1, GPE_PATH_FUSED = 2 };
+/* analytic base phi_n of the perturbation ansatz u = phi_n + s*NN: Hermite (refine/harmonic_pinn_simulation.py:95-119),
+ * box sine sqrt(2/L) sin((n+1) pi x / L) (refine/box_pinn_simulation.py:99-117), or three caller-supplied arrays
+ * (phi, phi', phi'' on the bound points: e.g. the Airy base of refine/gravity_well_pinn_simulation.py:97-173) */
+enum { GPE_BASE_HERMITE = 0, GPE_BASE_BOX = 1, GPE_BASE_PRECOMPUTED = 2 };
+/* hard boundary factor multiplying the network output in model.forward: none, or sin(pi x / env_L)
+ * (refine/box_pinn_simulation.py:119-130) */
+enum { GPE_ENV_NONE = 0, GPE_ENV_SIN = 1 };
 
 typedef struct gpe_engine gpe_engine; /* opaque */
 
@@ -92,6 +99,11 @@ typedef struct gpe_config {
      * stop_tol <= 0 and stop_patience <= 0 disable the respective test. */
     float stop_tol;
     int32_t stop_patience;
+    /* row f3 of SURVEY 8: other bases / hard boundary factor (1D) */
+    int32_t base_kind;            /* GPE_BASE_* (used when base_mode >= 0) */
+    int32_t envelope;             /* GPE_ENV_* */
+    float box_L;                  /* L of the box base */
+    float env_L;                  /* L of the sin(pi x / L) factor */
 } gpe_config;
 
 /* Per-step scalars (refine/...:364-381 keeps loss every 10 and lambda every 100 epochs). */
@@ -131,6 +143,9 @@ int gpe_reset_optimizer(gpe_engine* e, float lr);                    /* new Adam
 int gpe_bind_points(gpe_engine* e, const float* d_x, int64_t n_local, const float* d_V);
 int gpe_bind_boundary(gpe_engine* e, const float* d_xb, int64_t n_b, const float* d_target /* [n_b,out] or NULL = 0 */);
 int gpe_bind_orth(gpe_engine* e, int k, const float* d_psi_k /* [n_local] or NULL to clear */);
+/* GPE_BASE_PRECOMPUTED: phi, phi', phi'' of the base on the bound points, each [n_local].  The boundary term then uses no
+ * base: fold phi(x_b) into the boundary target. */
+int gpe_bind_base(gpe_engine* e, const float* d_phi, const float* d_phi1, const float* d_phi2);
 
 /* ---- forward-only entry points ---------------------------------------------------------------- */
 /* model.forward(x) (refine/...:121-125): d_out [n, out] row-major */

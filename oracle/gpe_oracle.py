@@ -39,6 +39,8 @@ import numpy as np
 # ----------------------------------------------------------------------------------------
 POT_HARMONIC, POT_GAUSSIAN, POT_PERIODIC, POT_PRECOMPUTED, POT_NONE = 0, 1, 2, 3, 4
 SCHED_CONST, SCHED_COSINE_LOSS, SCHED_PLATEAU = 0, 1, 2
+BASE_HERMITE, BASE_BOX, BASE_PRECOMPUTED = 0, 1, 2
+ENV_NONE, ENV_SIN = 0, 1
 
 
 @dataclass
@@ -67,6 +69,10 @@ class Problem:
     w_sym: float = 0.0
     w_orth: float = 0.0
     sym_sign: float = 1.0                      # +1 even mode, -1 odd mode
+    base_kind: int = BASE_HERMITE              # refine/box_pinn_simulation.py:99-117 (BOX); caller arrays (PRECOMPUTED)
+    envelope: int = ENV_NONE                   # ENV_SIN: forward = NN * sin(pi x / env_L)  (refine/box_pinn_simulation.py:119-130)
+    box_L: float = 1.0
+    env_L: float = 1.0
     dx: float = 1.0                            # quadrature weight
     n_global: int = 0                          # N used in the means (0 -> len(x))
 
@@ -198,6 +204,24 @@ def hermite_base(x1: np.ndarray, n: int, deriv_mode: int = 0):
     return phi, phi1, phi2
 
 
+def base_functions(pb: Problem, x1: np.ndarray, base_pre=None):
+    """phi_n, phi_n', phi_n'' of the configured base on 1D points."""
+    dt = x1.dtype
+    if pb.base_kind == BASE_PRECOMPUTED:
+        return tuple(np.asarray(a, dtype=dt) for a in base_pre)
+    if pb.base_kind == BASE_BOX:                       # refine/box_pinn_simulation.py:99-117, 141-180
+        k = dt.type((pb.base_mode + 1) * math.pi / pb.box_L)
+        a = dt.type(math.sqrt(2.0 / pb.box_L))
+        return a * np.sin(k * x1), a * k * np.cos(k * x1), -a * k * k * np.sin(k * x1)
+    return hermite_base(x1, pb.base_mode, pb.base_deriv)
+
+
+def envelope(pb: Problem, x1: np.ndarray):
+    dt = x1.dtype
+    k = dt.type(math.pi / pb.env_L)
+    return np.sin(k * x1), k * np.cos(k * x1), -k * k * np.sin(k * x1)
+
+
 def potential(pb: Problem, x: np.ndarray, V_pre: Optional[np.ndarray] = None) -> np.ndarray:
     dt = x.dtype
     if pb.potential == POT_PRECOMPUTED:
@@ -227,15 +251,20 @@ def _ipow(u, p: int):
 # ----------------------------------------------------------------------------------------
 # head: NN output jets -> u, H u, sums
 # ----------------------------------------------------------------------------------------
-def head_pde(pb: Problem, x: np.ndarray, out: np.ndarray, V_pre=None):
+def head_pde(pb: Problem, x: np.ndarray, out: np.ndarray, V_pre=None, base_pre=None):
     """out [C,N,n_out].  Returns dict with u, Hu ([N,n_out]), V, and the jets of u."""
     dt = x.dtype
     N, d = x.shape
     sc = dt.type(pb.perturb_scale)
+    if pb.envelope == ENV_SIN:                    # model.forward = network(x) * sin(pi x)  (box_pinn_simulation.py:127-130)
+        assert d == 1 and pb.n_out == 1
+        f, f1, f2 = (a[:, None] for a in envelope(pb, x[:, 0]))
+        o0, o1, o2 = out[0], out[1], out[2]
+        out = np.stack([o0 * f, o1 * f + o0 * f1, o2 * f + 2 * o1 * f1 + o0 * f2])
     U = sc * out                                  # harmonic_pinn_simulation.py:336-340
     if pb.base_mode >= 0:                         # get_complete_solution :127-134
         assert d == 1 and pb.n_out == 1
-        phi, phi1, phi2 = hermite_base(x[:, 0], pb.base_mode, pb.base_deriv)
+        phi, phi1, phi2 = base_functions(pb, x[:, 0], base_pre)
         U = U.copy()
         U[0, :, 0] += phi
         U[1, :, 0] += phi1
@@ -269,7 +298,7 @@ def head_pde(pb: Problem, x: np.ndarray, out: np.ndarray, V_pre=None):
 def loss_and_grad(pb: Problem, flat: np.ndarray, x: np.ndarray, x_bc: Optional[np.ndarray] = None,
                   bc_target: Optional[np.ndarray] = None, V_pre=None,
                   orth: Optional[np.ndarray] = None, want_grad: bool = True,
-                  shard_sums: Optional[dict] = None, phase: int = 0):
+                  shard_sums: Optional[dict] = None, phase: int = 0, base_pre=None):
     """One evaluation of the epoch body (harmonic_pinn_simulation.py:328-358 / notebook c10:L85-100)
     up to and including backward().  lambda is treated as a constant in the reverse pass
     (its branch is identically zero).
@@ -282,7 +311,7 @@ def loss_and_grad(pb: Problem, flat: np.ndarray, x: np.ndarray, x_bc: Optional[n
     N = pb.n_global if pb.n_global > 0 else N_loc
     params = unflatten(flat.astype(dt), pb.layers)
     out, cache = mlp_forward(params, x, pb.activation)
-    h = head_pde(pb, x, out, V_pre)
+    h = head_pde(pb, x, out, V_pre, base_pre)
     u, Hu, V, U = h['u'], h['Hu'], h['V'], h['U']
     acc = np.float64
     sums = dict(num=float((u * Hu).sum(dtype=acc)), den=float((u * u).sum(dtype=acc)))
@@ -313,9 +342,10 @@ def loss_and_grad(pb: Problem, flat: np.ndarray, x: np.ndarray, x_bc: Optional[n
     L_bc = 0.0
     if x_bc is not None and pb.w_bc != 0.0:
         ob, cb = mlp_forward(params, x_bc.astype(dt), pb.activation, value_only=True)
-        fb = dt.type(pb.bc_nn_scale) * ob[0]
-        if pb.base_mode >= 0:
-            fb = fb + hermite_base(x_bc[:, 0].astype(dt), pb.base_mode, pb.base_deriv)[0][:, None]
+        fenv_b = envelope(pb, x_bc[:, 0].astype(dt))[0][:, None] if pb.envelope == ENV_SIN else dt.type(1.0)
+        fb = dt.type(pb.bc_nn_scale) * fenv_b * ob[0]
+        if pb.base_mode >= 0 and pb.base_kind != BASE_PRECOMPUTED:
+            fb = fb + base_functions(pb, x_bc[:, 0].astype(dt))[0][:, None]
         tgt = np.zeros_like(fb) if bc_target is None else bc_target.astype(dt).reshape(fb.shape)
         eb = fb - tgt
         L_bc = float((eb * eb).mean(dtype=acc))                  # torch.mean over all elements (:210)
@@ -363,9 +393,13 @@ def loss_and_grad(pb: Problem, flat: np.ndarray, x: np.ndarray, x_bc: Optional[n
         Ub[2, :, 0] += Om * xx * rb[:, 1]
         Ub[1, :, 0] += -Om * yy * rb[:, 1]
     out_bar = dt.type(pb.perturb_scale) * Ub
+    if pb.envelope == ENV_SIN:                                   # adjoint of psi = o f
+        f, f1, f2 = (a[:, None] for a in envelope(pb, x[:, 0]))
+        u0, u1, u2 = out_bar[0], out_bar[1], out_bar[2]
+        out_bar = np.stack([f * u0 + f1 * u1 + f2 * u2, f * u1 + 2 * f1 * u2, f * u2])
     grad = mlp_backward(params, cache, out_bar).astype(acc)
     if x_bc is not None and pb.w_bc != 0.0:
-        ebar = (dt.type(pb.w_bc * 2.0 / eb.size) * eb) * dt.type(pb.bc_nn_scale)
+        ebar = (dt.type(pb.w_bc * 2.0 / eb.size) * eb) * dt.type(pb.bc_nn_scale) * fenv_b
         gbc = mlp_backward(params, cb, ebar[None], value_only=True).astype(acc)
         res['grad_bc'] = gbc                                     # identical on every shard
     else:
@@ -392,8 +426,8 @@ def assemble(pb: Problem, res: dict, sum_r2_total: Optional[float] = None, n_glo
                 orth=res['L_orth'], mu=res['lam'])
 
 
-def full_loss_and_grad(pb: Problem, flat, x, x_bc=None, bc_target=None, V_pre=None, orth=None):
-    res = loss_and_grad(pb, flat, x, x_bc, bc_target, V_pre, orth)
+def full_loss_and_grad(pb: Problem, flat, x, x_bc=None, bc_target=None, V_pre=None, orth=None, base_pre=None):
+    res = loss_and_grad(pb, flat, x, x_bc, bc_target, V_pre, orth, base_pre=base_pre)
     sc = assemble(pb, res)
     grad = res['grad_local'] + res['grad_bc']
     return sc, grad, res
@@ -489,13 +523,13 @@ def optimizer_step(st: OptState, flat: np.ndarray, grad: np.ndarray, loss: float
 
 
 def train_steps(pb: Problem, st: OptState, flat: np.ndarray, x, n_steps: int, x_bc=None, bc_target=None,
-                V_pre=None, orth=None, dtype=np.float32):
+                V_pre=None, orth=None, dtype=np.float32, base_pre=None):
     """n_steps epochs of the reference loop body; returns params and per-step scalar trace."""
     x = x.astype(dtype)
     flat = flat.astype(dtype)
     trace = []
     for _ in range(n_steps):
-        sc, grad, _ = full_loss_and_grad(pb, flat, x, x_bc, bc_target, V_pre, orth)
+        sc, grad, _ = full_loss_and_grad(pb, flat, x, x_bc, bc_target, V_pre, orth, base_pre)
         flat, gn, lr_used = optimizer_step(st, flat, grad, sc['loss'], dtype)
         sc.update(grad_norm=gn, lr=lr_used)
         trace.append(sc)
@@ -508,8 +542,10 @@ def eval_density(pb: Problem, flat: np.ndarray, x_test: np.ndarray, dx: float, a
     params = unflatten(flat.astype(dt), pb.layers)
     o, _ = mlp_forward(params, x_test, pb.activation, value_only=True)
     u = dt.type(pb.perturb_scale) * o[0]
+    if pb.envelope == ENV_SIN:
+        u = u * envelope(pb, x_test[:, 0])[0][:, None]
     if pb.base_mode >= 0:
-        u = u + hermite_base(x_test[:, 0], pb.base_mode, pb.base_deriv)[0][:, None]
+        u = u + base_functions(pb, x_test[:, 0])[0][:, None]
     nrm = np.sqrt((u * u).sum() * dt.type(dx))
     u = u / nrm
     if abs_mode0:

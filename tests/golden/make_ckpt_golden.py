@@ -29,3 +29,18 @@ for mode in modes:
     out[f"epochs_mode{mode}"] = int(d["epochs_history"][mode][0])
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", "fx_ckpt_harmonic_modes.npz"), **out)
 print({k: (v if np.ndim(v) == 0 else np.shape(v)) for k, v in out.items()})
+
+# ---- box_test/box_mode_zero_plot_data.pkl (refine/plot_box_potential_at_ground_state.py): modes 0,1 at gamma = 0 -------------
+d = ck.load_results("box_mode_zero_plot_data.pkl", os.path.join(REFDIR, "box_test"))
+out = dict(layers=np.array(d["models_state_dicts"][0][0]["layers"]), N=4000, lb=0.0, ub=1.0, perturb_const=0.01)
+modes = sorted(d["models_state_dicts"])
+out["modes"] = np.array(modes)
+for mode in modes:
+    md = d["models_state_dicts"][mode][0]
+    sd = md["state_dict"]
+    out[f"flat_mode{mode}"] = np.concatenate([sd[k].numpy().ravel() for k in sd]).astype(np.float32)
+    out[f"mu_mode{mode}"] = float(d["mu_table"][mode][0][1])
+    out[f"const_mode{mode}"] = float(d["constant_history"][mode])
+    out[f"epochs_mode{mode}"] = int(d["epochs_history"][mode][0])
+np.savez_compressed(os.path.join(ROOT, "tests", "golden", "fx_ckpt_box_modes.npz"), **out)
+print({k: (v if np.ndim(v) == 0 else np.shape(v)) for k, v in out.items()})

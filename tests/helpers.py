@@ -48,3 +48,14 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-300))
+
+
+def problem_from_box(fx, mode=None, const=None) -> go.Problem:
+    """refine/box_pinn_simulation.py flavour: ShiftedTanh, -u'' + gamma u^p on [0,1], forward = NN*sin(pi x), sine base."""
+    mode = int(fx["mode"]) if mode is None else mode
+    const = float(fx["normal_const"]) if const is None else const
+    return go.Problem(layers=[int(v) for v in fx["layers"]], activation=1, kinetic_coeff=1.0, potential=go.POT_NONE,
+                      gamma=float(fx["gamma"]) if "gamma" in fx else 0.0, p=int(fx["p"]) if "p" in fx else 3,
+                      base_mode=mode, base_kind=go.BASE_BOX, box_L=1.0, envelope=go.ENV_SIN, env_L=1.0,
+                      perturb_scale=float(fx["perturb_const"]) / const, bc_nn_scale=1.0, w_bc=10.0, w_norm=20.0,
+                      dx=float(fx["dx"]) if "dx" in fx else 1.0 / (int(fx["N"]) - 1))

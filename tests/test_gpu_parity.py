@@ -27,7 +27,8 @@ def cfg_from_problem(pb: go.Problem, **kw) -> GPEConfig:
              pot_k=pb.pot_k, omega_rot=pb.omega_rot, gamma=pb.gamma, p=pb.p, abs_power=pb.abs_power,
              base_mode=pb.base_mode, base_deriv=pb.base_deriv, perturb_scale=pb.perturb_scale,
              bc_nn_scale=pb.bc_nn_scale, w_pde=pb.w_pde, w_bc=pb.w_bc, w_norm=pb.w_norm, w_sym=pb.w_sym,
-             w_orth=pb.w_orth, sym_sign=pb.sym_sign, dx=pb.dx, n_global=pb.n_global)
+             w_orth=pb.w_orth, sym_sign=pb.sym_sign, dx=pb.dx, n_global=pb.n_global, base_kind=pb.base_kind,
+             envelope=pb.envelope, box_L=pb.box_L, env_L=pb.env_L)
     d.update(kw)
     return GPEConfig(**d)
 
@@ -366,3 +367,52 @@ def test_stored_reference_checkpoint_mu_table(mode):
         sc, _, _ = eng.residual(want_fields=False)
         assert abs(sc["mu"] - float(fx[f"mu_mode{mode}"])) < 5e-5, (path, sc["mu"])
         eng.close()
+
+
+@pytest.mark.parametrize("name", ["fx_box_m0_g0.npz", "fx_box_m1_g20.npz"])
+@pytest.mark.parametrize("path", ["generic", "fused"])
+def test_golden_box_oplevel(name, path):
+    """Row f3: box potential flavour (refine/box_pinn_simulation.py) -- engine vs the reference's own numbers and the oracle."""
+    fx = H.load_fx(name)
+    pb = H.problem_from_box(fx)
+    xb = np.array([[0.0], [1.0]])
+    eng = make_engine(pb, fx["flat0"], fx["x"], xb, path=PATHS[path])
+    fwd = eng.forward(torch.as_tensor(fx["x"], device="cuda")).cpu().numpy()
+    assert H.rel_err(fwd, fx["forward_out"]) < 1e-5                     # model.forward includes the sin(pi x) factor
+    rs, psi, res = eng.residual()
+    assert H.rel_err(psi.cpu().numpy(), fx["u"]) < 2e-6
+    assert abs(rs["mu"] - float(fx["lam"])) < 5e-5 * abs(float(fx["lam"]))
+    sc = eng.step()
+    assert abs(sc["loss"] - float(fx["total"])) < 1e-3 * max(float(fx["total"]), 1e-4)
+    osc, ograd, _ = go.full_loss_and_grad(pb, fx["flat0"].astype(np.float64), fx["x"].astype(np.float64), xb)
+    assert H.rel_err(eng.get_grad(), ograd) < 5e-5
+    assert H.rel_err(eng.get_grad(), fx["grad0"]) < 1e-3
+    eng.close()
+
+
+@pytest.mark.parametrize("mode", [0, 3])
+def test_stored_box_checkpoint_mu_table(mode):
+    fx = H.load_fx("fx_ckpt_box_modes.npz")
+    x = np.linspace(0.0, 1.0, int(fx["N"])).reshape(-1, 1)
+    pb = H.problem_from_box(fx, mode=mode, const=float(fx[f"const_mode{mode}"]))
+    eng = make_engine(pb, fx[f"flat_mode{mode}"], x, None)
+    sc, _, _ = eng.residual(want_fields=False)
+    assert abs(sc["mu"] - float(fx[f"mu_mode{mode}"])) < 1e-4 * float(fx[f"mu_mode{mode}"])
+    eng.close()
+
+
+def test_precomputed_base_equals_analytic_base():
+    """GPE_BASE_PRECOMPUTED (how the Airy base of refine/gravity_well_pinn_simulation.py enters): feeding the Hermite base as
+    three arrays must reproduce the analytic-base step exactly."""
+    kw = dict(layers=[1, 64, 64, 64, 1], activation=1, kinetic_coeff=1.0, pot_scale=1.0, gamma=3.0, base_mode=2,
+              perturb_scale=0.05, dx=12 / 499)
+    x, flat, x_bc = _inputs(kw, 500)
+    pb = go.Problem(**kw)
+    a = make_engine(pb, flat, x, None)
+    sa = a.step(); ga = a.get_grad()
+    phi, p1, p2 = go.hermite_base(x[:, 0].astype(np.float64), 2)
+    b = make_engine(go.Problem(**{**kw, "base_kind": go.BASE_PRECOMPUTED}), flat, x, None)
+    b.bind_base(phi, p1, p2)
+    sb = b.step(); gb = b.get_grad()
+    assert abs(sa["mu"] - sb["mu"]) < 1e-6 * abs(sa["mu"]) and abs(sa["loss"] - sb["loss"]) < 1e-5 * abs(sa["loss"])
+    assert H.rel_err(gb, ga) < 1e-5

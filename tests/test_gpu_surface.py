@@ -169,3 +169,18 @@ def test_mse_gradient_matches_oracle():
     sc = eng.mse_step()                                   # plain Adam: every weight moves by ~lr on the first step
     d = np.abs(eng.get_params() - flat)
     assert 0.5e-3 < np.median(d) < 1.5e-3 and abs(sc["loss"] - loss) < 1e-6
+
+
+def test_box_driver_known_answer():
+    """refine/box_pinn_simulation.py surface: gamma = 0 on [0,1] -> lambda = pi^2 (mode 0), 4 pi^2 (mode 1)."""
+    from gpe_pinn import box
+    torch.manual_seed(0)
+    X = np.linspace(0, 1, 1000).reshape(-1, 1)
+    out = box.train_gpe_model([0.0], [0, 1], 3, X, 0, 1, [1, 64, 64, 64, 1], 400, 1e-7, 0.01, potential_type="box", lr=1e-3,
+                              verbose=False, pretrain=None)
+    mu_table = out[1]
+    assert abs(mu_table[0][0][1] - np.pi ** 2) < 2e-3 * np.pi ** 2
+    assert abs(mu_table[1][0][1] - 4 * np.pi ** 2) < 2e-3 * 4 * np.pi ** 2
+    m = out[0][0][0.0]
+    f = m.forward(torch.tensor([[0.0], [1.0]], device="cuda")).cpu().numpy()
+    assert np.abs(f).max() < 1e-5                                  # hard boundary factor

@@ -129,3 +129,34 @@ def test_stored_reference_checkpoint_mu_table(mode):
     res = go.loss_and_grad(pb, fx[f"flat_mode{mode}"].astype(np.float64), x, want_grad=False)
     assert abs(res["lam"] - float(fx[f"mu_mode{mode}"])) < 3e-5
     assert abs(res["lam"] - (2 * mode + 1)) < 5e-5
+
+
+@pytest.mark.parametrize("name", ["fx_box_m0_g0.npz", "fx_box_m1_g20.npz"])
+def test_box_oplevel(name):
+    """Row f3: refine/box_pinn_simulation.py (sine base, hard boundary factor sin(pi x)) vs the oracle."""
+    fx = H.load_fx(name)
+    pb = H.problem_from_box(fx)
+    x = fx["x"].astype(np.float64)
+    flat = fx["flat0"].astype(np.float64)
+    sc, grad, res = go.full_loss_and_grad(pb, flat, x, np.array([[0.0], [1.0]]))
+    h = go.head_pde(pb, x, go.mlp_forward(go.unflatten(flat, pb.layers), x, pb.activation)[0])
+    assert H.rel_err(h["U"][0], fx["u"]) < 2e-6
+    assert H.rel_err(h["U"][1], fx["u_x"]) < 1e-5
+    assert H.rel_err(h["U"][2], fx["u_xx"]) < 1e-4
+    assert abs(sc["mu"] - float(fx["lam"])) < 5e-5 * abs(float(fx["lam"]))
+    assert abs(sc["pde"] - float(fx["pde_loss"])) < 1e-3 * max(float(fx["pde_loss"]), 1e-4)
+    assert abs(sc["loss"] - float(fx["total"])) < 1e-3 * max(float(fx["total"]), 1e-4)
+    assert H.rel_err(grad, fx["grad0"]) < 1e-3
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5])
+def test_stored_box_checkpoint_mu_table(mode):
+    """box_test/box_mode_zero_plot_data.pkl: stored weights reproduce the recorded lambda = ((n+1) pi)^2."""
+    fx = H.load_fx("fx_ckpt_box_modes.npz")
+    N = int(fx["N"])
+    x = np.linspace(0.0, 1.0, N).reshape(-1, 1)
+    pb = H.problem_from_box(fx, mode=mode, const=float(fx[f"const_mode{mode}"]))
+    res = go.loss_and_grad(pb, fx[f"flat_mode{mode}"].astype(np.float64), x, want_grad=False)
+    ref = float(fx[f"mu_mode{mode}"])
+    assert abs(res["lam"] - ref) < 2e-5 * ref
+    assert abs(res["lam"] - ((mode + 1) * np.pi) ** 2) < 1e-4 * ref
