@@ -27,7 +27,8 @@ import torch
 from . import _capi as capi
 from .engine import Engine, GPEConfig
 
-_POT = {"harmonic": capi.POT_HARMONIC, "gaussian": capi.POT_GAUSSIAN, "periodic": capi.POT_PERIODIC, "box": capi.POT_NONE}
+_POT = {"harmonic": capi.POT_HARMONIC, "gaussian": capi.POT_GAUSSIAN, "periodic": capi.POT_PERIODIC, "box": capi.POT_NONE,
+        "gravity_well": capi.POT_PRECOMPUTED}
 
 
 def _device():
@@ -156,6 +157,11 @@ class _PINNBase:
 
     def _extra_config(self) -> dict:
         return {}
+
+    def _bind_training_data(self, eng, X_np, X_dev, bpts):
+        """X_tensor / boundary_points of the training loop (refine/...:260-264)."""
+        eng.bind_points(X_dev)
+        eng.bind_boundary(bpts)
 
     def _get_engine(self, **over) -> Engine:
         key = tuple(sorted(over.items()))
@@ -303,6 +309,55 @@ class _BoxPINN(_RefinePINN):
         return super().pde_loss(inputs, predictions, gamma, p, potential_type, precomputed_potential)
 
 
+class _GravityWellPINN(_RefinePINN):
+    """refine/gravity_well_pinn_simulation.py:52-260: V = x on [0, ub]; base Psi_n = Ai(x + alpha_n) normalised on the grid,
+    Psi' from scipy's Ai', Psi'' by np.gradient (as the reference does, :141-173).  Like the reference, the base is computed on
+    the host with scipy and handed to the device as arrays (GPE_BASE_PRECOMPUTED); V = x goes in as a precomputed potential."""
+
+    def _extra_config(self):
+        return dict(base_kind=capi.BASE_PRECOMPUTED, potential=capi.POT_PRECOMPUTED)
+
+    @staticmethod
+    def _airy(x_np, n):
+        from scipy.special import ai_zeros, airy
+        alpha_n = ai_zeros(n + 1)[0][n]
+        return airy(x_np + alpha_n)
+
+    def airy_solution(self, x, n):
+        """:97-118 (normalised with dx of the points handed in -- including the two boundary points, quirk kept)."""
+        x_np = _as_np(x).astype(np.float64).reshape(-1)
+        psi = self._airy(x_np, n)[0]
+        dx = x_np[1] - x_np[0] if len(x_np) > 1 else 0.01
+        psi = psi / np.sqrt(np.sum(psi ** 2) * dx)
+        out = torch.tensor(psi.astype(np.float32), device=_device())
+        return out.reshape(x.shape) if isinstance(x, torch.Tensor) else out
+
+    def base_arrays(self, x_np, n):
+        """(phi, phi', phi'') exactly as get_complete_solution_with_derivatives builds them (:141-160)."""
+        x_np = np.asarray(x_np, np.float64).reshape(-1)
+        ai, aip, _, _ = self._airy(x_np, n)
+        dx = x_np[1] - x_np[0] if len(x_np) > 1 else 0.01
+        nf = np.sqrt(np.sum(ai ** 2) * dx)
+        return ((ai / nf).astype(np.float32), (aip / nf).astype(np.float32), np.gradient(aip / nf, dx).astype(np.float32))
+
+    def weighted_hermite(self, x, n):
+        return self.airy_solution(x, n)
+
+    def weighted_hermite_np(self, x, n):
+        return self.base_arrays(x, n)[0]
+
+    def compute_potential(self, x, potential_type="gravity_well", **kwargs):
+        if potential_type != "gravity_well":
+            raise ValueError(f"Unknown potential type: {potential_type}")
+        return x.clone()
+
+    def _bind_training_data(self, eng, X_np, X_dev, bpts):
+        eng.bind_points(X_dev, V=X_dev[:, 0].contiguous())
+        eng.bind_base(*self.base_arrays(X_np[:, 0], self.mode))
+        base_b = self.airy_solution(bpts, self.mode).reshape(-1, 1)
+        eng.bind_boundary(bpts, -base_b)               # e = base(x_b) + NN(x_b) - 0
+
+
 class _NotebookPINN(_PINNBase):
     """Gross_Pitaevskii_1D_power_Test.ipynb c6."""
     _flavor = _NOTEBOOK
@@ -445,8 +500,7 @@ def _refine_train(gamma_values, modes, p, X_train, lb, ub, layers, epochs, tol, 
                                     sched=capi.SCHED_COSINE_LOSS, T_0=200.0, T_mult=2.0, eta_min=1e-6,
                                     w_bc=10.0, w_norm=20.0, stop_tol=float(tol), stop_patience=2000,
                                     history_capacity=max(int(epochs), 1))
-            eng.bind_points(X_dev)
-            eng.bind_boundary(bpts)
+            model._bind_training_data(eng, X, X_dev, bpts)
             done = 0
             final_epoch = epochs
             while done < epochs:
@@ -583,6 +637,18 @@ def _box_train(gamma_values, modes, p, X_train, lb, ub, layers, epochs, tol, per
                          _cls=_BoxPINN, L=L, **kw)
 
 
+def _gravity_train(gamma_values, modes, p, X_train, lb, ub, layers, epochs, tol, perturb_const, potential_type="gravity_well",
+                   lr=1e-5, verbose=True, **kw):
+    """train_gpe_model of refine/gravity_well_pinn_simulation.py (same loop; sum/sum lambda == mean/mean)."""
+    if potential_type != "gravity_well":
+        raise ValueError(f"Unknown potential type: {potential_type}")
+    return _refine_train(gamma_values, modes, p, X_train, lb, ub, layers, epochs, tol, perturb_const, "gravity_well", lr,
+                         verbose, _cls=_GravityWellPINN, **kw)
+
+
+gravity_well = types.SimpleNamespace(GrossPitaevskiiPINN=_GravityWellPINN, train_gpe_model=_gravity_train,
+                                     advanced_initialization=_refine_advanced_initialization,
+                                     pretrain_on_analytical_solution=_refine_pretrain)
 box = types.SimpleNamespace(GrossPitaevskiiPINN=_BoxPINN, train_gpe_model=_box_train,
                             advanced_initialization=_refine_advanced_initialization,
                             pretrain_on_analytical_solution=_refine_pretrain)

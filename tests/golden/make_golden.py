@@ -319,3 +319,46 @@ if __name__ == "__main__" and os.environ.get("GOLDEN_BOX", "1") == "1":
     box = load_module("ref_refine_box", os.path.join(REF, "Gross-Pitaevskii/src/final/refine/box_pinn_simulation.py"))
     box_fixture(box, "m0_g0", [1, 64, 64, 64, 1], 400, 0, 0, 0.0, 3, 0.01)
     box_fixture(box, "m1_g20", [1, 64, 64, 64, 1], 400, 5, 1, 20.0, 3, 0.01)
+
+
+# ------------------------------------------------------------------------------------------------
+def gravity_fixture(gw, tag, layers, N, seed, mode, gamma, p, perturb_const):
+    """refine/gravity_well_pinn_simulation.py flavour (row f3): V = x on [0,35], Airy base (scipy, host), phi'' by np.gradient."""
+    torch.manual_seed(seed)
+    lb, ub = 0.0, 35.0
+    X = np.linspace(lb, ub, N).reshape(-1, 1)
+    dx = X[1, 0] - X[0, 0]
+    model = gw.GrossPitaevskiiPINN(layers, mode=mode, gamma=gamma)
+    model.apply(lambda m: gw.advanced_initialization(m, mode))
+    flat0 = flat_params(model)
+    X_tensor = torch.tensor(X, dtype=torch.float32, requires_grad=True)
+    bpts = torch.tensor([[lb], [ub]], dtype=torch.float32)
+    bvals = torch.zeros((2, 1), dtype=torch.float32)
+    u_nn = model.forward(X_tensor)
+    normal_const = torch.max(u_nn).detach().clone()
+    u_pred = perturb_const * (u_nn / normal_const)
+    u, u_x, u_xx = model.get_complete_solution_with_derivatives(X_tensor, u_pred)
+    with torch.no_grad():
+        zero = torch.zeros_like(u_pred)
+    b0, b1, b2 = model.get_complete_solution_with_derivatives(X_tensor, u_pred * 0.0)
+    pde_loss, lam = model.pde_loss(X_tensor, u_pred, gamma, p, "gravity_well")
+    bl = model.boundary_loss(bpts, bvals)
+    nl = model.normalization_loss(model.get_complete_solution(X_tensor, u_pred), dx)
+    total = pde_loss + 10.0 * bl + 20.0 * nl
+    model.zero_grad()
+    total.backward()
+    base_b = model.airy_solution(bpts, mode).detach().numpy()
+    fx = dict(layers=np.array(layers), N=N, seed=seed, mode=mode, gamma=gamma, p=p, perturb_const=perturb_const,
+              normal_const=float(normal_const), dx=dx, lb=lb, ub=ub, flat0=flat0, x=X.astype(np.float32),
+              base=b0.detach().numpy(), base_x=b1.detach().numpy(), base_xx=b2.detach().numpy(), base_boundary=base_b,
+              u=u.detach().numpy(), u_x=u_x.detach().numpy(), u_xx=u_xx.detach().numpy(),
+              lam=float(lam), pde_loss=float(pde_loss), bc_loss=float(bl), norm_loss=float(nl), total=float(total),
+              grad0=flat_grads(model))
+    np.savez_compressed(os.path.join(OUT, f"fx_gravity_{tag}.npz"), **fx)
+    print("wrote gravity", tag, "loss0", fx['total'], "lam0", fx['lam'], "normal_const", fx['normal_const'])
+
+
+if __name__ == "__main__" and os.environ.get("GOLDEN_GRAVITY", "1") == "1":
+    gw = load_module("ref_refine_gravity", os.path.join(REF, "Gross-Pitaevskii/src/final/refine/gravity_well_pinn_simulation.py"))
+    gravity_fixture(gw, "m0_g0", [1, 64, 64, 64, 1], 500, 0, 0, 0.0, 3, 0.01)
+    gravity_fixture(gw, "m1_g5", [1, 64, 64, 64, 1], 500, 3, 1, 5.0, 3, 0.01)

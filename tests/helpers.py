@@ -59,3 +59,11 @@ def problem_from_box(fx, mode=None, const=None) -> go.Problem:
                       base_mode=mode, base_kind=go.BASE_BOX, box_L=1.0, envelope=go.ENV_SIN, env_L=1.0,
                       perturb_scale=float(fx["perturb_const"]) / const, bc_nn_scale=1.0, w_bc=10.0, w_norm=20.0,
                       dx=float(fx["dx"]) if "dx" in fx else 1.0 / (int(fx["N"]) - 1))
+
+
+def problem_from_gravity(fx) -> go.Problem:
+    """refine/gravity_well_pinn_simulation.py flavour: V = x (fed as a precomputed potential), Airy base fed as arrays."""
+    return go.Problem(layers=[int(v) for v in fx["layers"]], activation=1, kinetic_coeff=1.0, potential=go.POT_PRECOMPUTED,
+                      gamma=float(fx["gamma"]), p=int(fx["p"]), base_mode=int(fx["mode"]), base_kind=go.BASE_PRECOMPUTED,
+                      perturb_scale=float(fx["perturb_const"]) / float(fx["normal_const"]), bc_nn_scale=1.0,
+                      w_bc=10.0, w_norm=20.0, dx=float(fx["dx"]))

@@ -416,3 +416,26 @@ def test_precomputed_base_equals_analytic_base():
     sb = b.step(); gb = b.get_grad()
     assert abs(sa["mu"] - sb["mu"]) < 1e-6 * abs(sa["mu"]) and abs(sa["loss"] - sb["loss"]) < 1e-5 * abs(sa["loss"])
     assert H.rel_err(gb, ga) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["fx_gravity_m0_g0.npz", "fx_gravity_m1_g5.npz"])
+def test_golden_gravity_well_oplevel(name):
+    """Row f3: gravity well (V = x, Airy base as precomputed arrays, boundary base folded into the target)."""
+    fx = H.load_fx(name)
+    pb = H.problem_from_gravity(fx)
+    x = fx["x"]
+    xb = np.array([[float(fx["lb"])], [float(fx["ub"])]], np.float32)
+    for path in ("generic", "fused"):
+        cfg = cfg_from_problem(pb, path=PATHS[path])
+        eng = Engine(cfg)
+        eng.set_params(fx["flat0"])
+        eng.bind_points(torch.as_tensor(x, device="cuda"), V=torch.as_tensor(x[:, 0].copy(), device="cuda"))
+        eng.bind_base(fx["base"][:, 0], fx["base_x"][:, 0], fx["base_xx"][:, 0])
+        eng.bind_boundary(torch.as_tensor(xb, device="cuda"), torch.as_tensor(-fx["base_boundary"].astype(np.float32), device="cuda"))
+        rs, psi, res = eng.residual()
+        assert H.rel_err(psi.cpu().numpy(), fx["u"]) < 2e-6
+        assert abs(rs["mu"] - float(fx["lam"])) < 5e-5 * abs(float(fx["lam"]))
+        sc = eng.step()
+        assert abs(sc["loss"] - float(fx["total"])) < 5e-4 * float(fx["total"])
+        assert H.rel_err(eng.get_grad(), fx["grad0"]) < 1e-3
+        eng.close()

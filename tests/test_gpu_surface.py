@@ -186,3 +186,15 @@ def test_box_driver_known_answer():
     m = out[0][0][0.0]
     f = m.forward(torch.tensor([[0.0], [1.0]], device="cuda")).cpu().numpy()
     assert np.abs(f).max() < 1e-5                                  # hard boundary factor
+
+
+def test_gravity_well_driver_known_answer():
+    """refine/gravity_well_pinn_simulation.py surface: V = x on [0,35], gamma = 0 -> lambda_n = -(n-th Airy zero): 2.33811, 4.08795.
+    The reference's own stored run reports 2.3451 / 4.1211 -- its phi'' comes from np.gradient on the grid."""
+    from gpe_pinn import gravity_well
+    torch.manual_seed(0)
+    X = np.linspace(0, 35, 4000).reshape(-1, 1)
+    out = gravity_well.train_gpe_model([0.0], [0, 1], 3, X, 0, 35, [1, 64, 64, 64, 1], 300, 1e-9, 0.01,
+                                       potential_type="gravity_well", lr=1e-3, verbose=False)
+    mu = out[1]
+    assert abs(mu[0][0][1] - 2.33811) < 2e-2 and abs(mu[1][0][1] - 4.08795) < 5e-2

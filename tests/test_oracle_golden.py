@@ -160,3 +160,20 @@ def test_stored_box_checkpoint_mu_table(mode):
     ref = float(fx[f"mu_mode{mode}"])
     assert abs(res["lam"] - ref) < 2e-5 * ref
     assert abs(res["lam"] - ((mode + 1) * np.pi) ** 2) < 1e-4 * ref
+
+
+@pytest.mark.parametrize("name", ["fx_gravity_m0_g0.npz", "fx_gravity_m1_g5.npz"])
+def test_gravity_well_oplevel(name):
+    """Row f3: refine/gravity_well_pinn_simulation.py (Airy base computed on the host with scipy there, arrays here)."""
+    fx = H.load_fx(name)
+    pb = H.problem_from_gravity(fx)
+    x = fx["x"].astype(np.float64)
+    base = (fx["base"][:, 0], fx["base_x"][:, 0], fx["base_xx"][:, 0])
+    xb = np.array([[float(fx["lb"])], [float(fx["ub"])]])
+    sc, grad, res = go.full_loss_and_grad(pb, fx["flat0"].astype(np.float64), x, xb, bc_target=-fx["base_boundary"],
+                                          V_pre=x[:, 0], base_pre=base)
+    assert H.rel_err(res["psi"], fx["u"]) < 2e-6
+    assert abs(sc["mu"] - float(fx["lam"])) < 5e-5 * abs(float(fx["lam"]))
+    assert abs(sc["bc"] - float(fx["bc_loss"])) < 1e-4 * max(float(fx["bc_loss"]), 1e-8)
+    assert abs(sc["loss"] - float(fx["total"])) < 5e-4 * float(fx["total"])
+    assert H.rel_err(grad, fx["grad0"]) < 1e-3
