@@ -410,7 +410,8 @@ def _refine_pretrain(model, mode, X_train, epochs=5000, lr=1e-3, verbose=False):
     X = _as_np(X_train).astype(np.float32)
     dev = _device()
     X_dev = torch.as_tensor(X, device=dev)
-    eng = model._get_engine(lr=float(lr), sched=capi.SCHED_CONST, w_bc=0.0)
+    # the fit involves no physics: no base, no potential (only the hard boundary factor of forward(), if any, stays)
+    eng = model._get_engine(lr=float(lr), sched=capi.SCHED_CONST, w_bc=0.0, potential=capi.POT_NONE, base_mode=-1)
     eng.reset_optimizer(float(lr))
     eng.bind_points(X_dev)
     target = model.weighted_hermite_np(X[:, 0], mode).reshape(-1, 1)
