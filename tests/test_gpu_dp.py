@@ -1,0 +1,76 @@
+"""world_size = 2 on ONE MI355X: two processes, each with its own HIP engine on cuda:0 and half of the collocation points,
+exchange the two step buffers with torch.distributed (gloo backend: NCCL/RCCL refuses two ranks on one device; the
+data-parallel protocol and the engine's three-phase API are exactly what bench.py runs over RCCL).  The result must equal
+the single-engine step on all points."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _case():
+    rng = np.random.default_rng(11)
+    layers = [2, 64, 64, 64, 1]
+    N = 6001                                         # odd: ragged shards, last tile partial
+    x = rng.uniform(-3, 3, (N, 2)).astype(np.float32)
+    xb = rng.uniform(-3, 3, (9, 2)).astype(np.float32)
+    P = sum(layers[i] * layers[i + 1] + layers[i + 1] for i in range(len(layers) - 1))
+    flat = (rng.normal(0, 0.3, P)).astype(np.float32)
+    kw = dict(layers=layers, gamma=40.0, dx=0.006, lr=1e-3, n_global=N)
+    return kw, x, xb, flat
+
+
+def _worker(rank, world, port, steps, out):
+    import torch.distributed as dist
+    import gpe_pinn
+    from gpe_pinn.dp import shard_points
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    kw, x, xb, flat = _case()
+    eng = gpe_pinn.Engine(gpe_pinn.GPEConfig(**kw, world_size=world), device=0)
+    eng.set_params(flat)
+    eng.bind_points(torch.as_tensor(shard_points(x, rank, world), device="cuda:0"))
+    eng.bind_boundary(torch.as_tensor(xb, device="cuda:0"))
+    trace = []
+    for _ in range(steps):
+        trace.append(eng.step_distributed(sync=True))
+    if rank == 0:
+        np.savez(out, flat=eng.get_params(), loss=[t["loss"] for t in trace], mu=[t["mu"] for t in trace],
+                 gn=[t["grad_norm"] for t in trace])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_one_gpu_equal_single_engine(tmp_path):
+    import torch.multiprocessing as mp
+    import gpe_pinn
+    steps, world = 3, 2
+    out = str(tmp_path / "dp_gpu.npz")
+    mp.get_context("spawn")
+    mp.spawn(_worker, args=(world, _free_port(), steps, out), nprocs=world, join=True)
+    got = np.load(out)
+    kw, x, xb, flat = _case()
+    eng = gpe_pinn.Engine(gpe_pinn.GPEConfig(**kw))
+    eng.set_params(flat)
+    eng.bind_points(torch.as_tensor(x, device="cuda"))
+    eng.bind_boundary(torch.as_tensor(xb, device="cuda"))
+    ref = [eng.step() for _ in range(steps)]
+    np.testing.assert_allclose(got["loss"], [t["loss"] for t in ref], rtol=2e-5)
+    np.testing.assert_allclose(got["mu"], [t["mu"] for t in ref], rtol=2e-6)
+    np.testing.assert_allclose(got["gn"], [t["grad_norm"] for t in ref], rtol=2e-5)
+    assert np.abs(got["flat"] - eng.get_params()).max() < 2e-5
