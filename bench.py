@@ -33,6 +33,7 @@ WORKLOADS = {
     # name: (layers, dim, points per GPU (grid), gamma, domain half-width)
     "ns_2d_4x64": dict(layers=[2, 64, 64, 64, 64, 1], grid=(1024, 1024), gamma=500.0, half=8.0),
     "cfg2_1d_4x64": dict(layers=[1, 64, 64, 64, 64, 1], grid=(65536,), gamma=100.0, half=10.0),
+    "cfg3_2d_5x128": dict(layers=[2, 128, 128, 128, 128, 128, 1], grid=(512, 256), gamma=500.0, half=8.0),
 }
 
 
@@ -199,13 +200,13 @@ def main():
                        "parallelism": f"dp{world}", "kernel_path": "fused_mfma_f32_16x16x4"},
             "per_gpu_points_per_s": value / world,
             "final_loss": sc["loss"], "final_mu": sc["mu"],
-            "roofline": {"bound": "mfma", "kernel": "f_backward<64,5,1> (fused jet reverse pass)",
+            "roofline": {"bound": "mfma", "kernel": "f_backward<%d,%d,1> (fused jet reverse pass)" % (layers[1], 1 + 2 * layers[0]),
                          "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": (bmat_pt / 2.0 * (len(layers) - 3) / (len(layers) - 2) + 4.0 * (1 + 2 * layers[0]) + 4.0 * layers[0] + 8.0) * n_local,
                          "algorithmic_flop_per_point": 2.0 * f_fwd, "avg_launch_ms": bwd_s * 1e3,
                          "launches": prof["bwd_launches"]},
-            "roofline_forward": {"bound": "mfma", "kernel": "f_forward<64,5,1>", "achieved": ach_f,
+            "roofline_forward": {"bound": "mfma", "kernel": "f_forward<%d,%d,1>" % (layers[1], 1 + 2 * layers[0]), "achieved": ach_f,
                                  "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_f / FP32_MFMA_PEAK_TFLOPS,
                                  "algorithmic_flop_per_point": f_fwd, "avg_launch_ms": fwd_s * 1e3},
             "step_flop_per_point": flops_pt, "whole_step_tflops": flops_pt * value / world / 1e12,

@@ -194,6 +194,7 @@ struct gpe_engine {
     bool ext_exchange = false;
     bool fwd_wlds = false, bwd_wlds = false;      // hidden-hidden weights staged in LDS by the fused kernels
     bool bwd_racc = false;                        // reverse kernel keeps the H x H weight gradients in registers (1 wave/SIMD)
+    int nslab_g = 16;                             // H = 128: number of global-atomic gradient slabs
     bool prof = false;
     std::vector<hipEvent_t> ev_pool;      // pairs: [2i] start, [2i+1] stop
     std::vector<int> ev_kind;             // 0 forward, 1 reverse
@@ -291,6 +292,10 @@ static size_t fused_fwd_lds(gpe_engine* e) { return fused_small_bytes(e) + (e->f
 
 template <int HH, int CC>
 static void launch_f_forward(gpe_engine* e, Batch& b, unsigned grid, int store) {
+    if constexpr (HH > 64) {
+        F_LAUNCH(f_forward, HH, CC, false, grid, 256, fused_fwd_lds(e), e->nd, e->theta, e->Wpk, b.x, b.stored, b.O, b.n, b.ld, store);
+        return;
+    }
     if (e->fwd_wlds)
         F_LAUNCH(f_forward, HH, CC, true, grid, 256, fused_fwd_lds(e), e->nd, e->theta, e->Wpk, b.x, b.stored, b.O, b.n, b.ld, store);
     else
@@ -298,7 +303,11 @@ static void launch_f_forward(gpe_engine* e, Batch& b, unsigned grid, int store) 
 }
 template <int HH, int CC>
 static void launch_f_backward(gpe_engine* e, Batch& b, unsigned grid, size_t lds) {
-#define BARGS e->nd, e->theta, e->WpkT, b.x, b.stored, b.Ob, e->gslab, b.n, b.ld, e->Ppad
+    if constexpr (HH > 64) {
+        B_LAUNCH(HH, CC, false, 0, grid, 256, lds, e->nd, e->theta, e->WpkT, b.x, b.stored, b.Ob, e->gslab, b.n, b.ld, e->Ppad, e->nslab_g);
+        return;
+    } else {
+#define BARGS e->nd, e->theta, e->WpkT, b.x, b.stored, b.Ob, e->gslab, b.n, b.ld, e->Ppad, e->nslab_g
     if (e->bwd_racc) {
         switch (e->nd.n_lin - 2) {
             case 1: B_LAUNCH(HH, CC, true, 1, grid, 256, lds, BARGS); break;
@@ -310,6 +319,7 @@ static void launch_f_backward(gpe_engine* e, Batch& b, unsigned grid, size_t lds
     else
         B_LAUNCH(HH, CC, false, 0, grid, 256, lds, BARGS);
 #undef BARGS
+    }
 }
 
 // persistent grids: forward 256-thread blocks, 2 per CU; reverse 256-thread x 2 per CU, or 512-thread x 1 per CU (WLDS)
@@ -323,6 +333,7 @@ static unsigned fused_grid(gpe_engine* e, int64_t n, int waves_per_block, int bl
 }
 
 static size_t fused_bwd_lds(gpe_engine* e, int C) {
+    if (e->H > 64) return ((size_t)4 * e->H + (size_t)4 * C * F_TILE) * sizeof(float) + fused_small_bytes(e);
     const int nwaves = e->bwd_racc ? 4 : (e->bwd_wlds ? 8 : 4);
     const bool w = e->bwd_racc || e->bwd_wlds;
     return ((size_t)e->Ppad + 4 * (size_t)e->H + (size_t)nwaves * C * F_TILE) * sizeof(float) + fused_small_bytes(e) +
@@ -363,7 +374,15 @@ static int mlp_forward(gpe_engine* e, Batch& b, bool store) {
         if (rc) return rc;
         unsigned grid = fused_grid(e, b.n, 4, 2);
         if (mark) prof_mark(e, 0, true);
-        if (e->H == 64) { DISPATCH_C(b.C, launch_f_forward<64, CC>(e, b, grid, store ? 1 : 0)); }
+        if (e->H == 128) {      // wide layers: one wave per SIMD, C <= 5 (checked at create)
+            grid = fused_grid(e, b.n, 4, 1);
+            switch (b.C) {
+                case 1: launch_f_forward<128, 1>(e, b, grid, store ? 1 : 0); break;
+                case 3: launch_f_forward<128, 3>(e, b, grid, store ? 1 : 0); break;
+                default: launch_f_forward<128, 5>(e, b, grid, store ? 1 : 0); break;
+            }
+        }
+        else if (e->H == 64) { DISPATCH_C(b.C, launch_f_forward<64, CC>(e, b, grid, store ? 1 : 0)); }
         else            { DISPATCH_C(b.C, launch_f_forward<32, CC>(e, b, grid, store ? 1 : 0)); }
         if (mark) prof_mark(e, 0, false);
     } else {
@@ -388,11 +407,22 @@ static int mlp_backward(gpe_engine* e, Batch& b) {
         size_t lds = fused_bwd_lds(e, b.C);
         const bool mark = e->prof && (&b == &e->main);
         if (mark) prof_mark(e, 1, true);
-        if (e->H == 64) { DISPATCH_C(b.C, launch_f_backward<64, CC>(e, b, grid, lds)); }
+        int nred = (int)grid;
+        if (e->H == 128) {
+            grid = fused_grid(e, b.n, 4, 1);
+            nred = e->nslab_g;
+            HIPCHK(e, hipMemsetAsync(e->gslab, 0, (size_t)e->nslab_g * e->Ppad * sizeof(float), e->stream));
+            switch (b.C) {
+                case 1: launch_f_backward<128, 1>(e, b, grid, lds); break;
+                case 3: launch_f_backward<128, 3>(e, b, grid, lds); break;
+                default: launch_f_backward<128, 5>(e, b, grid, lds); break;
+            }
+        }
+        else if (e->H == 64) { DISPATCH_C(b.C, launch_f_backward<64, CC>(e, b, grid, lds)); }
         else            { DISPATCH_C(b.C, launch_f_backward<32, CC>(e, b, grid, lds)); }
         if (mark) prof_mark(e, 1, false);
         HIPCHK(e, hipGetLastError());
-        hipLaunchKernelGGL(k_grad_reduce, dim3(cdiv(e->P, 64)), dim3(1024), 0, e->stream, e->gslab, (int)grid, e->Ppad,
+        hipLaunchKernelGGL(k_grad_reduce, dim3(cdiv(e->P, 64)), dim3(1024), 0, e->stream, e->gslab, nred, e->Ppad,
                            e->P, e->grad);
     } else {
         const NetDesc& nd = e->nd;
@@ -527,7 +557,9 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
     const int Lh = c.n_layers - 2;
     size_t lds_need = ((size_t)e->Ppad + (size_t)(8 + c.n_layers + 2) * c.layers[1] + 8 + 4 * (1 + 2 * dim) * F_TILE) * sizeof(float);
     bool fused_ok = uniform && (H == 32 || H == 64) && Lh >= 2 && lds_need <= 160 * 1024;
-    if (c.path == GPE_PATH_FUSED && !fused_ok) CFAIL("fused path needs >=2 hidden layers of width 32 or 64 (and P*4 <= 160KB LDS)");
+    if (uniform && H == 128 && Lh >= 2 && dim <= 2) fused_ok = true;          // wide variant: global-atomic gradient slabs
+    if (c.path == GPE_PATH_FUSED && !fused_ok)
+        CFAIL("fused path needs >=2 hidden layers of one width: 32 or 64 (P*4 <= 160KB LDS), or 128 with dim <= 2");
     e->path = (c.path == GPE_PATH_GENERIC || !fused_ok) ? GPE_PATH_GENERIC : GPE_PATH_FUSED;
     e->H = H;
 #undef CFAIL
@@ -550,7 +582,7 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
               alloc((void**)&e->hist, (size_t)e->cap * sizeof(gpe_scalars)) && alloc((void**)&e->last, sizeof(gpe_scalars)) &&
               alloc((void**)&e->orth_dev, 8 * sizeof(float*));
     if (ok && e->path == GPE_PATH_FUSED) {
-        e->nslab = e->num_cu * 2;
+        e->nslab = (H == 128) ? e->nslab_g : e->num_cu * 2;
         ok = alloc((void**)&e->Wpk, (size_t)(Lh - 1) * H * H * 4) && alloc((void**)&e->WpkT, (size_t)(Lh - 1) * H * H * 4) &&
              alloc((void**)&e->gslab, (size_t)e->nslab * e->Ppad * 4);
         if (ok) {
@@ -559,12 +591,12 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
             const char* env = getenv("GPE_WLDS");                     // tuning switch: 0 = weights from L2, 1 = from LDS
             const bool want = env ? (atoi(env) != 0) : true;
             const size_t smallb = ((size_t)(4 + (Lh - 1) + no) * H + 8) * sizeof(float);
-            e->fwd_wlds = want && wb + smallb <= 64 * 1024;
+            e->fwd_wlds = want && H <= 64 && wb + smallb <= 64 * 1024;
             // reverse kernel: measured slower with 512-thread workgroups + LDS weights (5.40 vs 5.29 ms on NS): opt-in only
-            e->bwd_wlds = want && (!env || atoi(env) != 3) &&
+            e->bwd_wlds = want && H <= 64 && (!env || atoi(env) != 3) &&
                           ((size_t)e->Ppad + 4 * (size_t)H + 8 * (size_t)Cmain * F_TILE) * sizeof(float) + smallb + wb <= 160 * 1024;
             const char* envr = getenv("GPE_RACC");
-            e->bwd_racc = (!envr || atoi(envr) != 0) && (Lh - 1) >= 1 && (Lh - 1) <= 3 &&
+            e->bwd_racc = (!envr || atoi(envr) != 0) && H <= 64 && (Lh - 1) >= 1 && (Lh - 1) <= 3 &&
                           ((size_t)e->Ppad + 4 * (size_t)H + 4 * (size_t)Cmain * F_TILE) * sizeof(float) + smallb + wb <= 160 * 1024;
             // allow > 64 KB dynamic LDS
             const int lds_b = 160 * 1024, lds_f = 64 * 1024;
@@ -580,6 +612,9 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
             SETLDS(32, 1, 1); SETLDS(32, 3, 1); SETLDS(32, 5, 1); SETLDS(32, 7, 1);
             SETLDS(32, 1, 2); SETLDS(32, 3, 2); SETLDS(32, 5, 2); SETLDS(32, 7, 2);
 #undef SETLDS
+#define SETLDS128(CC, NO) (void)hipFuncSetAttribute((const void*)f_backward<128, CC, NO, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b)
+            SETLDS128(1, 1); SETLDS128(3, 1); SETLDS128(5, 1); SETLDS128(1, 2); SETLDS128(3, 2); SETLDS128(5, 2);
+#undef SETLDS128
         }
     }
     if (!ok) return bail(GPE_ERR_NOMEM);

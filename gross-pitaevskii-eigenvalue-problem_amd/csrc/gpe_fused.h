@@ -135,7 +135,7 @@ GPE_DEV void layer0_st(const float* w0s, const float (&xv)[3], int nt, int q, f3
 // WLDS: the packed hidden-hidden weights ((L-1)*H*H floats) are staged once per workgroup into LDS and the MFMA A
 // operands are read from there (ds_read_b128, ~100 cycles) instead of from L2 (~600 cycles) right before each use.
 template <int H, int C, int NOUT, bool WLDS>
-__global__ __launch_bounds__(256, (C <= 5 ? GPE_FWD_WAVES : 1)) void f_forward(NetDesc nd, const float* __restrict__ theta,
+__global__ __launch_bounds__(256, ((C <= 5 && H <= 64) ? GPE_FWD_WAVES : 1)) void f_forward(NetDesc nd, const float* __restrict__ theta,
                                                                  const float* __restrict__ Wpk,
                                                                  const float* __restrict__ x, float* __restrict__ stored,
                                                                  float* __restrict__ O, int64_t N, int64_t ld,
@@ -292,20 +292,25 @@ GPE_DEV unsigned long long stamp_now() {
 // H x H weight gradients in MFMA accumulators across all the tiles it processes -- the products dW += Zb X^T chain
 // straight into them and LDS float atomics (measured at ~0.4 lane-adds per clock per CU: the limiter of the NHH = 0
 // variant) are used only for the small parameters and once per wave at the end.
+// H > 64 ("GACC"): the parameter vector no longer fits LDS (266 KB for [2,128x5,1]); gradients are accumulated with
+// global float atomics into one of `nslab` L2-resident slabs (blockIdx % nslab) that the host zeroes before the launch --
+// 16 KB of atomic traffic per point for cfg3, well inside the chip's ~1.3 TB/s atomic rate at the kernel's compute rate.
 template <int H, int C, int NOUT, bool WLDS, int NHH>
-__global__ __launch_bounds__((NHH > 0 ? 256 : (WLDS ? 512 : 256)), (NHH > 0 ? 1 : (C <= 5 ? GPE_BWD_WAVES : 1))) void f_backward(NetDesc nd, const float* __restrict__ theta,
+__global__ __launch_bounds__((NHH > 0 ? 256 : (WLDS ? 512 : 256)), ((NHH > 0 || H > 64) ? 1 : (C <= 5 ? GPE_BWD_WAVES : 1))) void f_backward(NetDesc nd, const float* __restrict__ theta,
                                                                   const float* __restrict__ WpkT,
                                                                   const float* __restrict__ x,
                                                                   const float* __restrict__ stored,
                                                                   const float* __restrict__ Ob, float* __restrict__ gslab,
-                                                                  int64_t N, int64_t ld, int Ppad) {
+                                                                  int64_t N, int64_t ld, int Ppad, int nslab) {
     constexpr int D = (C - 1) / 2, NT = H / 16, NF = NT * 4;
     constexpr int NTHR = (NHH > 0) ? 256 : (WLDS ? 512 : 256);
     constexpr bool RACC = NHH > 0;
+    constexpr bool GACC = H > 64;
     static_assert(!RACC || WLDS, "register accumulation variant keeps W^T in LDS");
+    static_assert(!GACC || (!RACC && !WLDS), "wide layers: global accumulation, weights from L2");
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* gacc = lds;
-    float* g0 = lds + Ppad;
+    float* gacc = GACC ? gslab + (size_t)(blockIdx.x % nslab) * Ppad : lds;
+    float* g0 = GACC ? lds : lds + Ppad;
     const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4;
     const int wib = threadIdx.x >> 6;
     float* TT = g0 + 4 * H + wib * (C * F_TILE);      // C transposition tiles, private to this wave
@@ -319,7 +324,8 @@ __global__ __launch_bounds__((NHH > 0 ? 256 : (WLDS ? 512 : 256)), (NHH > 0 ? 1 
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const float* Wo = w0s + (4 + L - 1) * H;                // LDS copy of W_out
 
-    for (int i = threadIdx.x; i < Ppad + 4 * H; i += NTHR) gacc[i] = 0.f;      // gacc and g0 are contiguous
+    if constexpr (GACC) { for (int i = threadIdx.x; i < 4 * H; i += NTHR) g0[i] = 0.f; }
+    else { for (int i = threadIdx.x; i < Ppad + 4 * H; i += NTHR) gacc[i] = 0.f; }      // gacc and g0 are contiguous
     stage_layer0<H>(w0s, theta, nd, NTHR);
     if constexpr (WLDS) {
         const int n4 = (L - 1) * H * H / 4;
@@ -532,7 +538,7 @@ __global__ __launch_bounds__((NHH > 0 ? 256 : (WLDS ? 512 : 256)), (NHH > 0 ? 1 
                         }
                         // LDS accumulate; columns XOR-swizzled by the row quad so that the 4 rows a wave touches per
                         // instruction fall into different banks (undone when the slab is written)
-                        const int col = (16 * kt + m) ^ (((nt * 4 + q) & (NT - 1)) << 4);
+                        const int col = GACC ? (16 * kt + m) : ((16 * kt + m) ^ (((nt * 4 + q) & (NT - 1)) << 4));
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             atomicAdd(&gacc[nd.offW[j] + (16 * nt + 4 * q + r) * H + col], dw0[r] + dw1[r]);
@@ -582,6 +588,14 @@ __global__ __launch_bounds__((NHH > 0 ? 256 : (WLDS ? 512 : 256)), (NHH > 0 ? 1 
                 }
     }
     __syncthreads();
+    if constexpr (GACC) {                               // only the padded layer-0 block lives in LDS
+        for (int i = threadIdx.x; i < 4 * H; i += NTHR) {
+            const int n = i >> 2, k = i & 3;
+            if (k == 3) atomicAdd(&gacc[nd.offB[0] + n], g0[i]);
+            else if (k < dim) atomicAdd(&gacc[nd.offW[0] + n * dim + k], g0[i]);
+        }
+        return;
+    }
     float* slab = gslab + (size_t)blockIdx.x * Ppad;
     const int first = nd.offW[1];                       // layer-0 parameters occupy [0, (dim+1) H)
     const int hid0 = nd.offW[1], hid1 = nd.offW[L];   // hidden-hidden maps 1..L-1 live in [hid0, hid1): H*H weights + H biases each
