@@ -41,16 +41,17 @@ class gpe_config(C.Structure):
         ("path", C.c_int32), ("world_size", C.c_int32), ("history_capacity", C.c_int32),
         ("stop_tol", C.c_float), ("stop_patience", C.c_int32),
         ("base_kind", C.c_int32), ("envelope", C.c_int32), ("box_L", C.c_float), ("env_L", C.c_float),
+        ("w_riesz", C.c_float), ("reserved_cfg", C.c_int32),
     ]
 
 
 class gpe_scalars(C.Structure):
     _fields_ = [(n, C.c_double) for n in
                 ("loss", "pde", "bc", "norm", "sym", "orth", "mu", "num", "den", "sum_r2", "integral",
-                 "grad_norm", "lr", "step")] + [("reserved", C.c_double * 2)]
+                 "grad_norm", "lr", "step", "nonfinite", "riesz")]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+        return {n: getattr(self, n) for n, _ in self._fields_}
 
 
 _vp, _i64, _int, _f = C.c_void_p, C.c_int64, C.c_int, C.c_float
@@ -103,6 +104,7 @@ SYMBOLS = {
     "gpe_set_lr": (_int, [_vp, _f]),
     "gpe_set_perturb_scale": (_int, [_vp, _f]),
     "gpe_set_n_global": (_int, [_vp, _i64]),
+    "gpe_set_loss_weights": (_int, [_vp, _P(C.c_float)]),
     "gpe_profile_enable": (_int, [_vp, _int]),
     "gpe_profile_read": (_int, [_vp, _P(C.c_double)]),
     "gpe_step_cost": (_int, [_vp, _P(C.c_double), _P(C.c_double)]),

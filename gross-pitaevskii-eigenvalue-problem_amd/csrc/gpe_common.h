@@ -30,7 +30,7 @@ struct Phys {
     int base_mode, base_deriv, base_kind, envelope;
     float box_L, env_L;
     float perturb_scale, bc_nn_scale;
-    float w_pde, w_bc, w_norm, w_sym, w_orth, sym_sign;
+    float w_pde, w_bc, w_norm, w_sym, w_orth, sym_sign, w_riesz;
     float dx;
     double n_global;                 // N of the means
     float inv_world;                 // 1/world_size: scales the replicated boundary batch
@@ -38,7 +38,7 @@ struct Phys {
 };
 
 // Indices into the double "sums" exchange buffer (all-reduced over ranks between phase 1 and 2).
-enum { S_NUM = 0, S_DEN = 1, S_SYM = 2, S_ORTH0 = 3, /* ..S_ORTH0+3 */ S_COUNT = 8 };
+enum { S_NUM = 0, S_DEN = 1, S_SYM = 2, S_ORTH0 = 3, /* ..S_ORTH0+3 */ S_RZ_K = 7, S_RZ_P = 8, S_RZ_I = 9, S_COUNT = 12 };
 // Local (replicated, never exchanged) double scalars.
 enum { LS_BC_SE2 = 0, LS_BC_CNT = 1, LS_COUNT = 4 };
 // Tail of the float gradient exchange buffer.

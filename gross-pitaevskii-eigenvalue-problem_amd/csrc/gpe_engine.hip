@@ -78,10 +78,11 @@ __global__ __launch_bounds__(1024) void k_update(int P, float* __restrict__ thet
         double sym = ph.w_sym != 0.f ? sums[S_SYM] / ph.n_global : 0.0;
         double orth = 0.0;
         for (int j = 0; j < ph.n_orth; ++j) { double oj = sums[S_ORTH0 + j] * ph.dx; orth += oj * oj; }
-        double loss = ph.w_pde * pde + ph.w_bc * bc + ph.w_norm * nrm + ph.w_sym * sym + ph.w_orth * orth;
+        double riesz = ph.w_riesz != 0.f ? (sums[S_RZ_K] + sums[S_RZ_P] + sums[S_RZ_I]) / den : 0.0;
+        double loss = ph.w_pde * pde + ph.w_bc * bc + ph.w_norm * nrm + ph.w_sym * sym + ph.w_orth * orth + ph.w_riesz * riesz;
         if (mse_mode) {           // pre-training: loss = mean((NN - target)^2); plain Adam (no clip, no scheduler, no early stop)
             loss = (double)grad[P + GT_MSE_SE2] / (ph.n_global * ph.n_out);
-            lam = 0.0; pde = 0.0; nrm = 0.0; bc = 0.0; sym = 0.0; orth = 0.0;
+            lam = 0.0; pde = 0.0; nrm = 0.0; bc = 0.0; sym = 0.0; orth = 0.0; riesz = 0.0;
         }
         int skip = !(isfinite(loss) && isfinite(gn));
         const int frozen = do_update && od->stopped;
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(1024) void k_update(int P, float* __restrict__ thet
         gpe_scalars r;
         r.loss = loss; r.pde = pde; r.bc = bc; r.norm = nrm; r.sym = sym; r.orth = orth; r.mu = lam;
         r.num = num; r.den = den; r.sum_r2 = sr2; r.integral = I; r.grad_norm = gn; r.lr = lr;
-        r.step = (double)step; r.reserved[0] = skip ? 1.0 : 0.0; r.reserved[1] = 0.0;
+        r.step = (double)step; r.nonfinite = skip ? 1.0 : 0.0; r.riesz = riesz;
         if (!frozen) *last = r;
         if (do_update && !frozen) {
             if (!skip) {
@@ -164,6 +165,7 @@ struct Batch {
     float* Ob = nullptr;
     float* u = nullptr;            // [n_out][ld]  (main batch)
     float* Hu = nullptr;
+    float* ux = nullptr;           // [ld] du/dx (Riesz term, 1D)
     float* stored = nullptr;       // fused: fragment-native stored activations
     std::vector<float*> S;         // generic: per hidden layer [C][H][ld]
     float* A0 = nullptr;           // generic adjoint ping/pong [C][maxW][ld]
@@ -242,6 +244,7 @@ static int setup_batch(gpe_engine* e, Batch& b, const float* x, int64_t n, int C
     if (with_head) {
         if ((rc = dev_alloc(e, &b, &b.u, (size_t)no * b.ld))) return rc;
         if ((rc = dev_alloc(e, &b, &b.Hu, (size_t)no * b.ld))) return rc;
+        if ((rc = dev_alloc(e, &b, &b.ux, (size_t)b.ld))) return rc;
     }
     const int L = e->nd.n_lin - 1;
     if (e->path == GPE_PATH_FUSED) {
@@ -462,7 +465,7 @@ static void fill_phys(gpe_engine* e) {
     p.base_kind = c.base_kind; p.envelope = c.envelope; p.box_L = c.box_L > 0.f ? c.box_L : 1.f; p.env_L = c.env_L > 0.f ? c.env_L : 1.f;
     p.perturb_scale = c.perturb_scale; p.bc_nn_scale = c.bc_nn_scale;
     p.w_pde = c.w_pde; p.w_bc = c.w_bc; p.w_norm = c.w_norm; p.w_sym = c.w_sym; p.w_orth = c.w_orth;
-    p.sym_sign = c.sym_sign; p.dx = c.dx;
+    p.sym_sign = c.sym_sign; p.dx = c.dx; p.w_riesz = c.w_riesz;
     p.n_global = (double)(c.n_global > 0 ? c.n_global : (e->main.n > 0 ? e->main.n : 1));
     p.inv_world = 1.0f / (float)(c.world_size > 0 ? c.world_size : 1);
     int no = 0;
@@ -536,6 +539,7 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
     if (c.base_kind < 0 || c.base_kind > GPE_BASE_PRECOMPUTED) CFAIL("Unknown base kind: %d", c.base_kind);
     if (c.envelope < 0 || c.envelope > GPE_ENV_SIN) CFAIL("Unknown envelope: %d", c.envelope);
     if (c.envelope != GPE_ENV_NONE && (dim != 1 || no != 1)) CFAIL("the boundary factor needs dim=1, out=1");
+    if (c.w_riesz != 0.f && (dim != 1 || no != 1)) CFAIL("the Riesz energy term needs dim=1, out=1");
     for (int i = 1; i < c.n_layers - 1; ++i)
         if (c.layers[i] < 1 || c.layers[i] > 1024) CFAIL("hidden width %d out of range", c.layers[i]);
     NetDesc& nd = e->nd;
@@ -800,7 +804,7 @@ static int launch_head_pde(gpe_engine* e) {
     Batch& b = e->main;
     dim3 g(head_grid(e, b.n));
     DISPATCH_C(b.C, hipLaunchKernelGGL((k_head_pde<CC>), g, dim3(256), 0, e->stream, e->ph, e->base_norm, b.x, b.V, b.O,
-                                        (const float* const*)e->orth_dev, b.u, b.Hu, e->sums(), b.n, b.ld));
+                                        (const float* const*)e->orth_dev, b.u, b.Hu, b.ux, e->sums(), b.n, b.ld));
     HIPCHK(e, hipGetLastError());
     return GPE_OK;
 }
@@ -808,7 +812,7 @@ static int launch_seed_pde(gpe_engine* e, float* d_resid, int want_seeds) {
     Batch& b = e->main;
     dim3 g(head_grid(e, b.n));
     DISPATCH_C(b.C, hipLaunchKernelGGL((k_seed_pde<CC>), g, dim3(256), 0, e->stream, e->ph, b.x, b.V,
-                                        (const float* const*)e->orth_dev, b.u, b.Hu, e->sums(), b.Ob, d_resid, e->dsc(),
+                                        (const float* const*)e->orth_dev, b.u, b.Hu, b.ux, e->sums(), b.Ob, d_resid, e->dsc(),
                                         b.n, b.ld, want_seeds));
     HIPCHK(e, hipGetLastError());
     return GPE_OK;
@@ -951,7 +955,7 @@ int gpe_read_scalars(gpe_engine* e, gpe_scalars* out) {
     if (!e || !out) return GPE_ERR_INVALID;
     HIPCHK(e, hipMemcpyAsync(out, e->last, sizeof *out, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
-    if (out->reserved[0] != 0.0) FAIL(e, GPE_ERR_NONFINITE, "non-finite loss or gradient at step %lld; parameters not updated", (long long)out->step + 1);
+    if (out->nonfinite != 0.0) FAIL(e, GPE_ERR_NONFINITE, "non-finite loss or gradient at step %lld; parameters not updated", (long long)out->step + 1);
     return GPE_OK;
 }
 
@@ -1019,6 +1023,14 @@ int gpe_set_power(gpe_engine* e, int p) {
     e->cfg.p = p; fill_phys(e); return GPE_OK;
 }
 int gpe_set_perturb_scale(gpe_engine* e, float s) { if (!e) return GPE_ERR_INVALID; e->cfg.perturb_scale = s; fill_phys(e); return GPE_OK; }
+int gpe_set_loss_weights(gpe_engine* e, const float w[6]) {
+    if (!e || !w) return GPE_ERR_INVALID;
+    if (w[5] != 0.f && (e->nd.dim != 1 || e->nd.n_out != 1)) FAIL(e, GPE_ERR_INVALID, "the Riesz energy term needs dim=1, out=1");
+    if ((w[3] != 0.f) != (e->cfg.w_sym != 0.f)) FAIL(e, GPE_ERR_INVALID, "the symmetry term cannot be switched on/off after bind_points");
+    e->cfg.w_pde = w[0]; e->cfg.w_bc = w[1]; e->cfg.w_norm = w[2]; e->cfg.w_sym = w[3]; e->cfg.w_orth = w[4]; e->cfg.w_riesz = w[5];
+    fill_phys(e);
+    return GPE_OK;
+}
 int gpe_set_n_global(gpe_engine* e, int64_t n) { if (!e) return GPE_ERR_INVALID; e->cfg.n_global = n; fill_phys(e); return GPE_OK; }
 int gpe_set_lr(gpe_engine* e, float lr) {
     if (!e) return GPE_ERR_INVALID;

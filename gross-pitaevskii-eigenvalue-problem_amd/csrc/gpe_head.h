@@ -37,11 +37,12 @@ template <int C>
 __global__ __launch_bounds__(256) void k_head_pde(Phys ph, float base_norm, const float* __restrict__ x,
                                                   const float* __restrict__ Vpre, const float* __restrict__ O,
                                                   const float* const* __restrict__ orth, float* __restrict__ u_out,
-                                                  float* __restrict__ Hu_out, double* __restrict__ sums, int64_t N,
-                                                  int64_t ld) {
+                                                  float* __restrict__ Hu_out, float* __restrict__ ux_out,
+                                                  double* __restrict__ sums, int64_t N, int64_t ld) {
     constexpr int D = (C - 1) / 2;
     __shared__ double red[4];
     double num = 0.0, den = 0.0, so[GPE_MAX_ORTH] = {0.0, 0.0, 0.0, 0.0};
+    double rzk = 0.0, rzp = 0.0, rzi = 0.0;
     // grid-stride: few workgroups, one double atomic each per sum (same-address atomics serialise at ~25 ns apiece)
     for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < N; m += (int64_t)gridDim.x * 256) {
         float xv[3] = {0.f, 0.f, 0.f};
@@ -79,6 +80,21 @@ __global__ __launch_bounds__(256) void k_head_pde(Phys ph, float base_norm, cons
             den += (double)(u * u);
         }
         for (int j = 0; j < ph.n_orth; ++j) so[j] += (double)(orth[j][m] * U[0][0]);
+        if constexpr (C == 3) {
+            if (ph.w_riesz != 0.f) {            // Paper nb c6:L163-174
+                const float u = U[0][0], ux = U[0][1];
+                ux_out[m] = ux;
+                rzk += 0.5 * (double)(ux * ux);
+                rzp += (double)(V * u * u);
+                rzi += (double)(ph.gamma / (float)(ph.p + 1) * ipowf(fabsf(u), ph.p + 1));
+            }
+        }
+    }
+    if (ph.w_riesz != 0.f) {
+        double t;
+        t = block_sum_256(rzk, red); if (threadIdx.x == 0) atomicAdd(&sums[S_RZ_K], t);
+        t = block_sum_256(rzp, red); if (threadIdx.x == 0) atomicAdd(&sums[S_RZ_P], t);
+        t = block_sum_256(rzi, red); if (threadIdx.x == 0) atomicAdd(&sums[S_RZ_I], t);
     }
     double r = block_sum_256(num, red);
     if (threadIdx.x == 0) atomicAdd(&sums[S_NUM], r);
@@ -96,6 +112,7 @@ template <int C>
 __global__ __launch_bounds__(256) void k_seed_pde(Phys ph, const float* __restrict__ x, const float* __restrict__ Vpre,
                                                   const float* const* __restrict__ orth,
                                                   const float* __restrict__ u_in, const float* __restrict__ Hu_in,
+                                                  const float* __restrict__ ux_in,
                                                   const double* __restrict__ sums, float* __restrict__ Ob,
                                                   float* __restrict__ resid_out, double* __restrict__ sum_r2, int64_t N,
                                                   int64_t ld, int want_seeds) {
@@ -140,6 +157,16 @@ __global__ __launch_bounds__(256) void k_seed_pde(Phys ph, const float* __restri
                 Ub[0] = ub[o];
 #pragma unroll
                 for (int j = 0; j < D; ++j) { Ub[1 + j] = 0.f; Ub[1 + D + j] = -ph.kin * rb[o]; }
+                if constexpr (C == 3) {
+                    if (ph.w_riesz != 0.f) {    // d(w_riesz E)/du, /du_x with E = (K + Pv + Ig)/den
+                        const float den = (float)sums[S_DEN];
+                        const float E = (float)((sums[S_RZ_K] + sums[S_RZ_P] + sums[S_RZ_I]) / sums[S_DEN]);
+                        const float uu = u[0];
+                        const float sg = uu < 0.f ? -1.f : 1.f;
+                        Ub[0] += ph.w_riesz * ((2.f * V * uu + ph.gamma * sg * ipowf(fabsf(uu), ph.p)) - 2.f * E * uu) / den;
+                        Ub[1] += ph.w_riesz * ux_in[m] / den;
+                    }
+                }
                 if (ph.complex_psi && ph.omega_rot != 0.f && D >= 2) {
                     float Om = ph.omega_rot;
                     if (o == 1) { Ub[2] += -Om * xv[0] * rb[0]; Ub[1] += Om * xv[1] * rb[0]; }

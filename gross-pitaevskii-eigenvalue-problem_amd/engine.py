@@ -73,6 +73,7 @@ class GPEConfig:
     envelope: int = capi.ENV_NONE
     box_L: float = 1.0
     env_L: float = 1.0
+    w_riesz: float = 0.0
 
     def to_c(self) -> capi.gpe_config:
         c = capi.gpe_config()
@@ -94,7 +95,7 @@ class GPEConfig:
         for name in ("kinetic_coeff", "pot_scale", "pot_a", "pot_v0", "pot_k", "omega_rot", "gamma", "perturb_scale",
                      "bc_nn_scale", "w_pde", "w_bc", "w_norm", "w_sym", "w_orth", "sym_sign", "dx", "lr", "beta1",
                      "beta2", "eps", "clip_norm", "T_0", "T_mult", "eta_min", "factor", "min_lr", "threshold",
-                     "stop_tol", "box_L", "env_L"):
+                     "stop_tol", "box_L", "env_L", "w_riesz"):
             setattr(c, name, float(getattr(self, name)))
         return c
 
@@ -362,6 +363,13 @@ class Engine:
     def set_perturb_scale(self, s: float):
         self.cfg.perturb_scale = float(s)
         self._chk(self.lib.gpe_set_perturb_scale(self._h, float(s)))
+
+    def set_loss_weights(self, w_pde, w_bc, w_norm, w_sym=0.0, w_orth=0.0, w_riesz=0.0):
+        """Change the loss weights between steps (what a host-side balancer such as ReLoBRaLo needs)."""
+        w = (C.c_float * 6)(w_pde, w_bc, w_norm, w_sym, w_orth, w_riesz)
+        self._chk(self.lib.gpe_set_loss_weights(self._h, w))
+        self.cfg.w_pde, self.cfg.w_bc, self.cfg.w_norm = float(w_pde), float(w_bc), float(w_norm)
+        self.cfg.w_sym, self.cfg.w_orth, self.cfg.w_riesz = float(w_sym), float(w_orth), float(w_riesz)
 
     def set_n_global(self, n: int):
         self.cfg.n_global = int(n)

@@ -104,6 +104,10 @@ typedef struct gpe_config {
     int32_t envelope;             /* GPE_ENV_* */
     float box_L;                  /* L of the box base */
     float env_L;                  /* L of the sin(pi x / L) factor */
+    /* row f4: Riesz energy term  w_riesz * E,  E = [1/2 sum u_x^2 + sum V u^2 + gamma/(p+1) sum |u|^(p+1)] / sum u^2
+     * (Notebooks/Paper/Gross_Pitaevskii_1D_Harmonic.ipynb c6:L133-183; 1D, real psi) */
+    float w_riesz;
+    int32_t reserved_cfg;
 } gpe_config;
 
 /* Per-step scalars (refine/...:364-381 keeps loss every 10 and lambda every 100 epochs). */
@@ -113,7 +117,8 @@ typedef struct gpe_scalars {
     double num, den, sum_r2, integral;
     double grad_norm, lr;
     double step;                  /* 1-based optimiser step that produced this record */
-    double reserved[2];
+    double nonfinite;             /* 1 when the loss or gradient was not finite (no update) */
+    double riesz;                 /* Riesz energy E (0 when w_riesz == 0) */
 } gpe_scalars;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
@@ -202,6 +207,9 @@ int gpe_set_power(gpe_engine* e, int p);
 int gpe_set_lr(gpe_engine* e, float lr);
 int gpe_set_perturb_scale(gpe_engine* e, float s);
 int gpe_set_n_global(gpe_engine* e, int64_t n_global);
+/* loss weights between steps: the host-side ReLoBRaLo balancing of src/gross_pitaevskii_2D_ReLoBRaLo.py:259-342 only needs the
+ * per-term scalars gpe_residual / gpe_step return and this setter.  w[6] = {pde, bc, norm, sym, orth, riesz}. */
+int gpe_set_loss_weights(gpe_engine* e, const float w[6]);
 
 /* Per-kernel timing with HIP events on the engine's stream (for bench.py's roofline object).  While enabled, every
  * launch of the two dominant kernels on the collocation batch (jet forward, jet reverse) is bracketed by events.

@@ -68,6 +68,7 @@ class Problem:
     w_norm: float = 20.0
     w_sym: float = 0.0
     w_orth: float = 0.0
+    w_riesz: float = 0.0                       # Riesz energy term (Paper nb c6:L133-183; 1D real psi)
     sym_sign: float = 1.0                      # +1 even mode, -1 odd mode
     base_kind: int = BASE_HERMITE              # refine/box_pinn_simulation.py:99-117 (BOX); caller arrays (PRECOMPUTED)
     envelope: int = ENV_NONE                   # ENV_SIN: forward = NN * sin(pi x / env_L)  (refine/box_pinn_simulation.py:119-130)
@@ -318,6 +319,11 @@ def loss_and_grad(pb: Problem, flat: np.ndarray, x: np.ndarray, x_bc: Optional[n
     n_orth = 0 if orth is None else orth.shape[0]
     for j in range(n_orth):
         sums[f'orth{j}'] = float((orth[j].astype(dt)[:, None] * u).sum(dtype=acc))
+    if pb.w_riesz != 0.0:                                        # Paper nb c6:L163-174 (dx cancels in the quotient)
+        assert d == 1 and pb.n_out == 1
+        sums['rz_k'] = float((0.5 * U[1] * U[1]).sum(dtype=acc))
+        sums['rz_p'] = float((V[:, None] * u * u).sum(dtype=acc))
+        sums['rz_i'] = float((dt.type(pb.gamma / (pb.p + 1)) * _ipow(np.abs(u), pb.p + 1)).sum(dtype=acc))
     # symmetry term: two value-only passes (notebook c6:L143-147)
     sym = None
     if pb.w_sym != 0.0:
@@ -353,7 +359,8 @@ def loss_and_grad(pb: Problem, flat: np.ndarray, x: np.ndarray, x_bc: Optional[n
     for j in range(n_orth):
         L_orth += (tot[f'orth{j}'] * pb.dx) ** 2
     L_sym = (tot['sym'] / N) if sym is not None else 0.0
-    res.update(L_norm=L_norm, L_bc=L_bc, L_orth=L_orth, L_sym=L_sym)
+    E_rz = (tot['rz_k'] + tot['rz_p'] + tot['rz_i']) / tot['den'] if pb.w_riesz != 0.0 else 0.0
+    res.update(L_norm=L_norm, L_bc=L_bc, L_orth=L_orth, L_sym=L_sym, L_riesz=E_rz)
     if not want_grad:
         return res
     # ---- seeds ----
@@ -384,6 +391,11 @@ def loss_and_grad(pb: Problem, flat: np.ndarray, x: np.ndarray, x_bc: Optional[n
     c = dt.type(pb.kinetic_coeff)
     for k in range(d):
         Ub[1 + d + k] = -c * rb
+    if pb.w_riesz != 0.0:
+        den = dt.type(tot['den'])
+        wz = dt.type(pb.w_riesz)
+        Ub[0] = Ub[0] + wz * ((2 * V[:, None] * u + g * np.sign(u + (u == 0)) * _ipow(np.abs(u), pb.p)) - 2 * dt.type(E_rz) * u) / den
+        Ub[1] = Ub[1] + wz * U[1] / den
     if pb.complex_psi and pb.omega_rot != 0.0:
         Om = dt.type(pb.omega_rot)
         xx, yy = x[:, 0], x[:, 1]
@@ -421,9 +433,9 @@ def assemble(pb: Problem, res: dict, sum_r2_total: Optional[float] = None, n_glo
     sr2 = res['sum_r2'] if sum_r2_total is None else sum_r2_total
     pde = sr2 / N
     total = (pb.w_pde * pde + pb.w_bc * res['L_bc'] + pb.w_norm * res['L_norm']
-             + pb.w_sym * res['L_sym'] + pb.w_orth * res['L_orth'])
+             + pb.w_sym * res['L_sym'] + pb.w_orth * res['L_orth'] + pb.w_riesz * res.get('L_riesz', 0.0))
     return dict(loss=total, pde=pde, bc=res['L_bc'], norm=res['L_norm'], sym=res['L_sym'],
-                orth=res['L_orth'], mu=res['lam'])
+                orth=res['L_orth'], mu=res['lam'], riesz=res.get('L_riesz', 0.0))
 
 
 def full_loss_and_grad(pb: Problem, flat, x, x_bc=None, bc_target=None, V_pre=None, orth=None, base_pre=None):

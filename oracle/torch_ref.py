@@ -145,6 +145,15 @@ def epoch_losses(pb: go.Problem, net: nn.Sequential, X: torch.Tensor, x_bc=None,
     norm = (integral - 1.0) ** 2
     total = pb.w_pde * pde + pb.w_norm * norm
     pieces = dict(pde=pde, norm=norm, lam=lam, u=u, r=r, Hu=Hu, nn=u_pred)
+    if getattr(pb, 'w_riesz', 0.0) != 0.0:                   # Notebooks/Paper/Gross_Pitaevskii_1D_Harmonic.ipynb c6:L157-177
+        dxr = X[1] - X[0]
+        norm_factor = torch.sum(u ** 2) * dxr
+        kinetic_term = 0.5 * torch.sum(grads1[0] ** 2) * dxr / norm_factor
+        potential_term = torch.sum(V * u ** 2) * dxr / norm_factor
+        interaction_term = 0.5 * (2.0 * pb.gamma / (pb.p + 1)) * torch.sum(torch.abs(u) ** (pb.p + 1)) * dxr / norm_factor
+        riesz = kinetic_term + potential_term + interaction_term
+        total = total + pb.w_riesz * riesz
+        pieces['riesz'] = riesz
     if x_bc is not None and pb.w_bc != 0.0:
         ub = pb.bc_nn_scale * net(x_bc)                      # :202 (quirk Q7: unscaled)
         if pb.base_mode >= 0:

@@ -362,3 +362,42 @@ if __name__ == "__main__" and os.environ.get("GOLDEN_GRAVITY", "1") == "1":
     gw = load_module("ref_refine_gravity", os.path.join(REF, "Gross-Pitaevskii/src/final/refine/gravity_well_pinn_simulation.py"))
     gravity_fixture(gw, "m0_g0", [1, 64, 64, 64, 1], 500, 0, 0, 0.0, 3, 0.01)
     gravity_fixture(gw, "m1_g5", [1, 64, 64, 64, 1], 500, 3, 1, 5.0, 3, 0.01)
+
+
+# ------------------------------------------------------------------------------------------------
+def paper_fixture(tag, layers, N, seed, gamma, p):
+    """Notebooks/Paper/Gross_Pitaevskii_1D_Harmonic.ipynb cell 6 (row f4): mode 0 loss = Riesz energy + PDE residual
+    + 10 bc + 20 norm + 5 sym (cell 8:L103-142); -1/2 u'' + 1/2 x^2 u + gamma |u|^(p-1) u."""
+    nbj = json.load(open(os.path.join(REF, "Notebooks/Paper/Gross_Pitaevskii_1D_Harmonic.ipynb")))
+    from scipy.special import hermite
+    ns = dict(torch=torch, nn=nn, np=np, math=math, hermite=hermite, device=torch.device("cpu"))
+    exec("".join(nbj["cells"][6]["source"]), ns)
+    torch.manual_seed(seed)
+    lb, ub = -10.0, 10.0
+    X = np.linspace(lb, ub, N).reshape(-1, 1)
+    dx = X[1, 0] - X[0, 0]
+    model = ns["GrossPitaevskiiPINN"](layers, mode=0, gamma=gamma)
+    flat0 = flat_params(model)
+    X_tensor = torch.tensor(X, dtype=torch.float32, requires_grad=True)
+    bpts = torch.tensor([[lb], [ub]], dtype=torch.float32)
+    bvals = torch.zeros((2, 1), dtype=torch.float32)
+    u_pred = model.forward(X_tensor)
+    riesz, lam_riesz, full_u = model.riesz_loss(X_tensor, u_pred, gamma, p, "harmonic")
+    pde_loss, _, lam_pde, _ = model.pde_loss(X_tensor, u_pred, gamma, p, "harmonic")
+    bl = model.boundary_loss(bpts, bvals)
+    nl = model.normalization_loss(model.get_complete_solution(X_tensor, u_pred), dx)
+    sl = model.symmetry_loss(X_tensor, lb, ub)
+    total = riesz + pde_loss + 10.0 * bl + 20.0 * nl + 5.0 * sl
+    model.zero_grad()
+    total.backward()
+    fx = dict(layers=np.array(layers), N=N, seed=seed, mode=0, gamma=gamma, p=p, dx=dx, lb=lb, ub=ub, flat0=flat0,
+              x=X.astype(np.float32), u=full_u.detach().numpy(), riesz=float(riesz), lam_pde=float(lam_pde),
+              pde_loss=float(pde_loss), bc_loss=float(bl), norm_loss=float(nl), sym_loss=float(sl), total=float(total),
+              grad0=flat_grads(model))
+    np.savez_compressed(os.path.join(OUT, f"fx_paper_{tag}.npz"), **fx)
+    print("wrote paper", tag, "riesz", fx["riesz"], "pde", fx["pde_loss"], "total", fx["total"])
+
+
+if __name__ == "__main__" and os.environ.get("GOLDEN_PAPER", "1") == "1":
+    paper_fixture("g10_p3", [1, 64, 64, 64, 1], 400, 0, 10.0, 3)
+    paper_fixture("g2_p2", [1, 32, 32, 32, 1], 300, 1, 2.0, 2)

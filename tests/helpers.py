@@ -67,3 +67,10 @@ def problem_from_gravity(fx) -> go.Problem:
                       gamma=float(fx["gamma"]), p=int(fx["p"]), base_mode=int(fx["mode"]), base_kind=go.BASE_PRECOMPUTED,
                       perturb_scale=float(fx["perturb_const"]) / float(fx["normal_const"]), bc_nn_scale=1.0,
                       w_bc=10.0, w_norm=20.0, dx=float(fx["dx"]))
+
+
+def problem_from_paper(fx) -> go.Problem:
+    """Notebooks/Paper/Gross_Pitaevskii_1D_Harmonic.ipynb flavour, mode 0: Riesz + PDE + 10 bc + 20 norm + 5 sym."""
+    return go.Problem(layers=[int(v) for v in fx["layers"]], activation=0, kinetic_coeff=0.5, potential=go.POT_HARMONIC,
+                      pot_scale=0.5, gamma=float(fx["gamma"]), p=int(fx["p"]), abs_power=True, base_mode=0, base_deriv=1,
+                      perturb_scale=1.0, w_bc=10.0, w_norm=20.0, w_sym=5.0, w_riesz=1.0, dx=float(fx["dx"]))

@@ -441,3 +441,25 @@ def test_golden_gravity_well_oplevel(name):
         assert abs(sc["loss"] - float(fx["total"])) < 5e-4 * float(fx["total"])
         assert H.rel_err(eng.get_grad(), fx["grad0"]) < 1e-3
         eng.close()
+
+
+@pytest.mark.parametrize("name", ["fx_paper_g10_p3.npz", "fx_paper_g2_p2.npz"])
+@pytest.mark.parametrize("path", ["generic", "fused"])
+def test_golden_paper_riesz_oplevel(name, path):
+    """Row f4: Riesz energy term -- engine vs the Paper notebook's own numbers and the oracle."""
+    fx = H.load_fx(name)
+    pb = H.problem_from_paper(fx)
+    eng = make_engine(pb, fx["flat0"], fx["x"], H.bc_points(fx), path=PATHS[path], w_riesz=pb.w_riesz)
+    sc = eng.step()
+    assert abs(sc["riesz"] - float(fx["riesz"])) < 2e-5 * abs(float(fx["riesz"]))
+    assert abs(sc["loss"] - float(fx["total"])) < 2e-4 * float(fx["total"])
+    osc, ograd, _ = go.full_loss_and_grad(pb, fx["flat0"].astype(np.float64), fx["x"].astype(np.float64), H.bc_points(fx))
+    assert H.rel_err(eng.get_grad(), ograd) < 5e-5
+    assert H.rel_err(eng.get_grad(), fx["grad0"]) < 5e-4
+    # loss-weight setter (host-side balancers): doubling every weight doubles the gradient
+    eng.set_params(fx["flat0"])
+    eng.set_loss_weights(2 * pb.w_pde, 2 * pb.w_bc, 2 * pb.w_norm, 2 * pb.w_sym, 0.0, 2 * pb.w_riesz)
+    sc2 = eng.step()
+    assert abs(sc2["loss"] - 2 * osc["loss"]) < 2e-4 * 2 * osc["loss"]
+    assert H.rel_err(eng.get_grad(), 2 * ograd) < 5e-5
+    eng.close()

@@ -198,3 +198,24 @@ def test_gravity_well_driver_known_answer():
                                        potential_type="gravity_well", lr=1e-3, verbose=False)
     mu = out[1]
     assert abs(mu[0][0][1] - 2.33811) < 2e-2 and abs(mu[1][0][1] - 4.08795) < 5e-2
+
+
+def test_relobralo_balanced_steps_run_and_descend():
+    """Row f4: host-side ReLoBRaLo balancing on the engine's per-term scalars (Riesz + PDE + bc + norm + sym)."""
+    from gpe_pinn.relobralo import ReLoBRaLo, balanced_step
+    torch.manual_seed(0)
+    fx = H.load_fx("fx_paper_g10_p3.npz")
+    cfg = gpe_pinn.GPEConfig(layers=[int(v) for v in fx["layers"]], gamma=10.0, p=3, abs_power=True, base_mode=0, base_deriv=1,
+                             w_bc=10.0, w_norm=20.0, w_sym=5.0, w_riesz=1.0, dx=float(fx["dx"]), lr=1e-3)
+    eng = gpe_pinn.Engine(cfg)
+    eng.set_params(fx["flat0"])
+    eng.bind_points(torch.as_tensor(fx["x"], device="cuda"))
+    eng.bind_boundary(torch.tensor([[-10.0], [10.0]], device="cuda"))
+    bal = ReLoBRaLo(5, [10.0, 1.0, 1.0, 20.0, 5.0])
+    first = None
+    for k in range(60):
+        sc, w = balanced_step(eng, bal)
+        first = first or sc
+        assert all(np.isfinite(v) for v in w.values())
+    assert sc["pde"] + sc["riesz"] < first["pde"] + first["riesz"]
+    eng.close()

@@ -177,3 +177,15 @@ def test_gravity_well_oplevel(name):
     assert abs(sc["bc"] - float(fx["bc_loss"])) < 1e-4 * max(float(fx["bc_loss"]), 1e-8)
     assert abs(sc["loss"] - float(fx["total"])) < 5e-4 * float(fx["total"])
     assert H.rel_err(grad, fx["grad0"]) < 1e-3
+
+
+@pytest.mark.parametrize("name", ["fx_paper_g10_p3.npz", "fx_paper_g2_p2.npz"])
+def test_paper_notebook_riesz_oplevel(name):
+    """Row f4: the Riesz-energy term of the Paper notebook (cell 6:L133-183) and its mode-0 loss (cell 8:L103-142)."""
+    fx = H.load_fx(name)
+    pb = H.problem_from_paper(fx)
+    sc, grad, res = go.full_loss_and_grad(pb, fx["flat0"].astype(np.float64), fx["x"].astype(np.float64), H.bc_points(fx))
+    assert abs(sc["riesz"] - float(fx["riesz"])) < 2e-5 * abs(float(fx["riesz"]))
+    assert abs(sc["pde"] - float(fx["pde_loss"])) < 5e-4 * float(fx["pde_loss"])
+    assert abs(sc["loss"] - float(fx["total"])) < 2e-4 * float(fx["total"])
+    assert H.rel_err(grad, fx["grad0"]) < 5e-4
