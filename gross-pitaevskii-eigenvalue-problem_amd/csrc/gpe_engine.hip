@@ -153,7 +153,12 @@ __global__ __launch_bounds__(1024) void k_update(int P, float* __restrict__ thet
     }
 }
 
-__global__ void k_tail(float* grad_tail, const double* dsc) { grad_tail[GT_SUM_R2] = (float)dsc[0]; grad_tail[GT_MSE_SE2] = (float)dsc[2]; }
+// closes the reverse phase: adds the boundary-batch gradient (computed on the side stream) and fills the exchange tail
+__global__ void k_tail(float* __restrict__ grad, const float* __restrict__ add, int P, const double* dsc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (add && i < P) grad[i] += add[i];
+    if (i == 0) { grad[P + GT_SUM_R2] = (float)dsc[0]; grad[P + GT_MSE_SE2] = (float)dsc[2]; }
+}
 
 // ------------------------------------------------------------------------------------------------
 struct Batch {
@@ -197,6 +202,16 @@ struct gpe_engine {
     bool fwd_wlds = false, bwd_wlds = false;      // hidden-hidden weights staged in LDS by the fused kernels
     bool bwd_racc = false;                        // reverse kernel keeps the H x H weight gradients in registers (1 wave/SIMD)
     int nslab_g = 16;                             // H = 128: number of global-atomic gradient slabs
+    int64_t stage_min_tiles = 0;                  // batches with fewer 16-point tiles use the unstaged kernels (latency-bound regime)
+    hipStream_t side = nullptr;                   // boundary batch runs here, concurrently with the collocation batch
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    float *gslab_bc = nullptr, *grad_bc = nullptr;
+    bool bc_inflight = false;
+    // gpe_run replays one captured step (hipGraph) while every by-value launch argument is unchanged
+    bool use_graph = false;
+    hipStream_t cap_stream = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    std::vector<char> graph_key;
     bool prof = false;
     std::vector<hipEvent_t> ev_pool;      // pairs: [2i] start, [2i+1] stop
     std::vector<int> ev_kind;             // 0 forward, 1 reverse
@@ -229,7 +244,8 @@ static int dev_alloc(gpe_engine* e, Batch* b, T** out, size_t count) {
     return GPE_OK;
 }
 
-static int setup_batch(gpe_engine* e, Batch& b, const float* x, int64_t n, int C, bool with_head, const float* V) {
+static int setup_batch(gpe_engine* e, Batch& b, const float* x, int64_t n, int C, bool with_head, const float* V,
+                       bool with_store = true) {
     if (b.n == n && b.C == C && b.O) { b.x = x; b.V = V; return GPE_OK; }
     HIPCHK(e, hipStreamSynchronize(e->stream));
     float* keep_xown = nullptr;
@@ -249,7 +265,7 @@ static int setup_batch(gpe_engine* e, Batch& b, const float* x, int64_t n, int C
     const int L = e->nd.n_lin - 1;
     if (e->path == GPE_PATH_FUSED) {
         int64_t ntiles = (n + 15) / 16;
-        size_t cnt = (size_t)ntiles * (L - 1) * C * e->H * 16;
+        size_t cnt = with_store ? (size_t)ntiles * (L - 1) * C * e->H * 16 : 0;     // forward-only batches keep nothing
         if ((rc = dev_alloc(e, &b, &b.stored, cnt ? cnt : 4))) return rc;
     } else {
         int maxW = 1;
@@ -291,18 +307,25 @@ static size_t fused_small_bytes(gpe_engine* e) {       // = small_count() of gpe
     size_t n = (size_t)(4 + (e->nd.n_lin - 2) + e->nd.n_out) * e->H + 4;
     return ((n + 3) & ~(size_t)3) * sizeof(float);
 }
-static size_t fused_fwd_lds(gpe_engine* e) { return fused_small_bytes(e) + (e->fwd_wlds ? fused_w_bytes(e) : 0); }
+static bool staged_batch(gpe_engine* e, const Batch& b) { return (b.n + 15) / 16 >= e->stage_min_tiles; }
+static size_t fused_fwd_lds(gpe_engine* e, bool staged) { return fused_small_bytes(e) + (e->fwd_wlds && staged ? fused_w_bytes(e) : 0); }
 
 template <int HH, int CC>
 static void launch_f_forward(gpe_engine* e, Batch& b, unsigned grid, int store) {
     if constexpr (HH > 64) {
-        F_LAUNCH(f_forward, HH, CC, false, grid, 256, fused_fwd_lds(e), e->nd, e->theta, e->Wpk, b.x, b.stored, b.O, b.n, b.ld, store);
+        F_LAUNCH(f_forward, HH, CC, false, grid, 256, fused_fwd_lds(e, false), e->nd, e->theta, e->Wpk, b.x, b.stored, b.O, b.n, b.ld, store);
         return;
     }
-    if (e->fwd_wlds)
-        F_LAUNCH(f_forward, HH, CC, true, grid, 256, fused_fwd_lds(e), e->nd, e->theta, e->Wpk, b.x, b.stored, b.O, b.n, b.ld, store);
+    if (e->fwd_wlds && staged_batch(e, b))
+        F_LAUNCH(f_forward, HH, CC, true, grid, 256, fused_fwd_lds(e, true), e->nd, e->theta, e->Wpk, b.x, b.stored, b.O, b.n, b.ld, store);
     else
-        F_LAUNCH(f_forward, HH, CC, false, grid, 256, fused_fwd_lds(e), e->nd, e->theta, e->Wpk, b.x, b.stored, b.O, b.n, b.ld, store);
+        F_LAUNCH(f_forward, HH, CC, false, grid, 256, fused_fwd_lds(e, false), e->nd, e->theta, e->Wpk, b.x, b.stored, b.O, b.n, b.ld, store);
+}
+// reverse-kernel variant for one batch: 2 = weight gradients in registers (1 wave/SIMD), 1 = 512-thread LDS-weight variant,
+// 0 = plain (LDS-atomic gradients, weights from L2; also the fastest when every wave sees only a tile or two)
+static int bwd_kind(gpe_engine* e, const Batch& b) {
+    if (e->H > 64 || !staged_batch(e, b)) return 0;
+    return e->bwd_racc ? 2 : (e->bwd_wlds ? 1 : 0);
 }
 template <int HH, int CC>
 static void launch_f_backward(gpe_engine* e, Batch& b, unsigned grid, size_t lds) {
@@ -311,13 +334,14 @@ static void launch_f_backward(gpe_engine* e, Batch& b, unsigned grid, size_t lds
         return;
     } else {
 #define BARGS e->nd, e->theta, e->WpkT, b.x, b.stored, b.Ob, e->gslab, b.n, b.ld, e->Ppad, e->nslab_g
-    if (e->bwd_racc) {
+    const int kind = bwd_kind(e, b);
+    if (kind == 2) {
         switch (e->nd.n_lin - 2) {
             case 1: B_LAUNCH(HH, CC, true, 1, grid, 256, lds, BARGS); break;
             case 2: B_LAUNCH(HH, CC, true, 2, grid, 256, lds, BARGS); break;
             default: B_LAUNCH(HH, CC, true, 3, grid, 256, lds, BARGS); break;
         }
-    } else if (e->bwd_wlds)
+    } else if (kind == 1)
         B_LAUNCH(HH, CC, true, 0, grid, 512, lds, BARGS);
     else
         B_LAUNCH(HH, CC, false, 0, grid, 256, lds, BARGS);
@@ -335,10 +359,10 @@ static unsigned fused_grid(gpe_engine* e, int64_t n, int waves_per_block, int bl
     return (unsigned)blocks;
 }
 
-static size_t fused_bwd_lds(gpe_engine* e, int C) {
+static size_t fused_bwd_lds(gpe_engine* e, int C, int kind) {
     if (e->H > 64) return ((size_t)4 * e->H + (size_t)4 * C * F_TILE) * sizeof(float) + fused_small_bytes(e);
-    const int nwaves = e->bwd_racc ? 4 : (e->bwd_wlds ? 8 : 4);
-    const bool w = e->bwd_racc || e->bwd_wlds;
+    const int nwaves = kind == 1 ? 8 : 4;
+    const bool w = kind != 0;
     return ((size_t)e->Ppad + 4 * (size_t)e->H + (size_t)nwaves * C * F_TILE) * sizeof(float) + fused_small_bytes(e) +
            (w ? fused_w_bytes(e) : 0);
 }
@@ -351,6 +375,19 @@ static int ensure_packed(gpe_engine* e) {
                        e->WpkT);
     HIPCHK(e, hipGetLastError());
     e->packed_dirty = false;
+    return GPE_OK;
+}
+
+// zero the step accumulators (+ repack weights when stale) in one launch
+static int launch_begin(gpe_engine* e) {
+    int n_pack = 0;
+    if (e->path == GPE_PATH_FUSED && e->packed_dirty) n_pack = (e->nd.n_lin - 2) * e->H * e->H;
+    const int n_dbl = S_COUNT + LS_COUNT + 4, n_grad = e->P + GT_COUNT, n_bc = e->P;
+    const int n = std::max(std::max(n_pack, n_dbl), n_grad);
+    hipLaunchKernelGGL(k_begin, dim3(cdiv(n, 256)), dim3(256), 0, e->stream, e->nd, e->H, e->theta, e->Wpk, e->WpkT, n_pack,
+                       e->dbl, n_dbl, e->grad, n_grad, e->grad_bc, n_bc);
+    HIPCHK(e, hipGetLastError());
+    if (n_pack) e->packed_dirty = false;
     return GPE_OK;
 }
 
@@ -406,8 +443,9 @@ static int mlp_forward(gpe_engine* e, Batch& b, bool store) {
 static int mlp_backward(gpe_engine* e, Batch& b) {
     if (b.n <= 0) return GPE_OK;
     if (e->path == GPE_PATH_FUSED) {
-        unsigned grid = e->bwd_racc ? fused_grid(e, b.n, 4, 1) : (e->bwd_wlds ? fused_grid(e, b.n, 8, 1) : fused_grid(e, b.n, 4, 2));
-        size_t lds = fused_bwd_lds(e, b.C);
+        const int kind = bwd_kind(e, b);
+        unsigned grid = kind == 2 ? fused_grid(e, b.n, 4, 1) : (kind == 1 ? fused_grid(e, b.n, 8, 1) : fused_grid(e, b.n, 4, 2));
+        size_t lds = fused_bwd_lds(e, b.C, kind);
         const bool mark = e->prof && (&b == &e->main);
         if (mark) prof_mark(e, 1, true);
         int nred = (int)grid;
@@ -599,6 +637,8 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
             // reverse kernel: measured slower with 512-thread workgroups + LDS weights (5.40 vs 5.29 ms on NS): opt-in only
             e->bwd_wlds = want && H <= 64 && (!env || atoi(env) != 3) &&
                           ((size_t)e->Ppad + 4 * (size_t)H + 8 * (size_t)Cmain * F_TILE) * sizeof(float) + smallb + wb <= 160 * 1024;
+            const char* envs = getenv("GPE_STAGE_MIN_TILES");
+            e->stage_min_tiles = envs ? atoll(envs) : (int64_t)e->num_cu * 8;   // measured crossover: 2 tiles per wave at 1 wave/SIMD
             const char* envr = getenv("GPE_RACC");
             e->bwd_racc = (!envr || atoi(envr) != 0) && H <= 64 && (Lh - 1) >= 1 && (Lh - 1) <= 3 &&
                           ((size_t)e->Ppad + 4 * (size_t)H + 4 * (size_t)Cmain * F_TILE) * sizeof(float) + smallb + wb <= 160 * 1024;
@@ -621,6 +661,21 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
 #undef SETLDS128
         }
     }
+    if (ok) {
+        ok = alloc((void**)&e->grad_bc, (size_t)e->P * 4);
+        if (ok && e->path == GPE_PATH_FUSED) ok = alloc((void**)&e->gslab_bc, (size_t)e->nslab * e->Ppad * 4);
+        const char* envg = getenv("GPE_GRAPH");
+        e->use_graph = envg && atoi(envg) != 0;    // opt-in: measured 6 % slower than plain launches on ROCm 7.2 (141 vs 133 us/step)
+        const char* envq = getenv("GPE_SIDE_STREAM");
+        if (ok && (!envq || atoi(envq) != 0)) {
+            if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) {
+                e->err = "side stream / events could not be created";
+                return bail(GPE_ERR_HIP);
+            }
+        }
+    }
     if (!ok) return bail(GPE_ERR_NOMEM);
     fill_phys(e);
     int rc = reset_opt(e, c.lr);
@@ -629,20 +684,28 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
     return GPE_OK;
 }
 
+static void graph_drop(gpe_engine* e);
+
 void gpe_destroy(gpe_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
+    if (e->side) { (void)hipStreamSynchronize(e->side); (void)hipStreamDestroy(e->side); }
+    graph_drop(e);
+    if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     free_batch(e->main); free_batch(e->bc); free_batch(e->sym); free_batch(e->aux); free_batch(e->mse);
     for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
     if (e->ext_exchange) { e->grad = nullptr; e->dbl = nullptr; }
-    void* ps[] = {e->theta, e->am, e->av, e->grad, e->dbl, e->od, e->hist, e->last, (void*)e->orth_dev, e->Wpk, e->WpkT, e->gslab};
+    void* ps[] = {e->theta, e->am, e->av, e->grad, e->dbl, e->od, e->hist, e->last, (void*)e->orth_dev, e->Wpk, e->WpkT, e->gslab, e->gslab_bc, e->grad_bc};
     for (void* p : ps) if (p) (void)hipFree(p);
     delete e;
 }
 
 int gpe_synchronize(gpe_engine* e) {
     if (!e) return GPE_ERR_INVALID;
+    if (e->side) HIPCHK(e, hipStreamSynchronize(e->side));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     return GPE_OK;
 }
@@ -754,7 +817,7 @@ int gpe_bind_base(gpe_engine* e, const float* d_phi, const float* d_phi1, const 
 
 // ---- forward-only ----------------------------------------------------------------------------------
 static int aux_forward(gpe_engine* e, const float* d_x, int64_t n, int C) {
-    int rc = setup_batch(e, e->aux, d_x, n, C, true, nullptr);
+    int rc = setup_batch(e, e->aux, d_x, n, C, true, nullptr, /*with_store=*/false);
     if (rc) return rc;
     return mlp_forward(e, e->aux, false);
 }
@@ -818,14 +881,16 @@ static int launch_seed_pde(gpe_engine* e, float* d_resid, int want_seeds) {
     return GPE_OK;
 }
 
+static int bc_fork(gpe_engine* e, bool with_backward);
+
 int gpe_step_begin(gpe_engine* e) {
     if (!e) return GPE_ERR_INVALID;
     if (e->main.n <= 0) FAIL(e, GPE_ERR_STATE, "step before bind_points");
     if (e->cfg.base_mode >= 0 && e->cfg.base_kind == GPE_BASE_PRECOMPUTED && !e->orth_host[4])
         FAIL(e, GPE_ERR_STATE, "precomputed base requested but gpe_bind_base was not called");
     int rc;
-    HIPCHK(e, hipMemsetAsync(e->dbl, 0, (S_COUNT + LS_COUNT + 4) * sizeof(double), e->stream));
-    HIPCHK(e, hipMemsetAsync(e->grad, 0, ((size_t)e->P + GT_COUNT) * sizeof(float), e->stream));
+    if ((rc = launch_begin(e))) return rc;
+    if ((rc = bc_fork(e, true))) return rc;
     if ((rc = mlp_forward(e, e->main, true))) return rc;
     if ((rc = launch_head_pde(e))) return rc;
     if (e->cfg.w_sym != 0.f) {
@@ -838,14 +903,48 @@ int gpe_step_begin(gpe_engine* e) {
     return GPE_OK;
 }
 
-static int bc_terms(gpe_engine* e, bool with_backward) {
+// Boundary batch (refine/harmonic_pinn_simulation.py:197-210): forward, loss + seeds, reverse.  It does not depend on mu, so it
+// is forked onto the side stream at the start of the step and overlaps the collocation batch; its gradient lands in grad_bc
+// and k_tail adds it after the join.
+static int bc_fork(gpe_engine* e, bool with_backward) {
+    e->bc_inflight = false;
     if (e->bc.n <= 0 || e->cfg.w_bc == 0.f) return GPE_OK;
-    int rc;
-    if ((rc = mlp_forward(e, e->bc, true))) return rc;
-    hipLaunchKernelGGL(k_head_seed_bc, dim3(cdiv(e->bc.n, 256)), dim3(256), 0, e->stream, e->ph, e->base_norm, e->bc.x,
-                       e->bc_target, e->bc.O, e->bc.Ob, e->lsums(), e->bc.n, e->bc.ld);
+    int rc = ensure_packed(e);
+    if (rc) return rc;
+    hipStream_t s0 = e->stream;
+    float *g0 = e->grad, *sl0 = e->gslab;
+    if (e->side) {
+        HIPCHK(e, hipEventRecord(e->ev_fork, s0));
+        HIPCHK(e, hipStreamWaitEvent(e->side, e->ev_fork, 0));
+        e->stream = e->side;
+    }
+    e->grad = e->grad_bc;
+    if (e->gslab_bc) e->gslab = e->gslab_bc;
+    auto body = [&]() -> int {
+        int r;
+        if ((r = mlp_forward(e, e->bc, true))) return r;
+        hipLaunchKernelGGL(k_head_seed_bc, dim3(cdiv(e->bc.n, 256)), dim3(256), 0, e->stream, e->ph, e->base_norm, e->bc.x,
+                           e->bc_target, e->bc.O, e->bc.Ob, e->lsums(), e->bc.n, e->bc.ld);
+        HIPCHK(e, hipGetLastError());
+        if (with_backward && (r = mlp_backward(e, e->bc))) return r;
+        return GPE_OK;
+    };
+    rc = body();
+    e->stream = s0; e->grad = g0; e->gslab = sl0;
+    if (rc) return rc;
+    if (e->side) HIPCHK(e, hipEventRecord(e->ev_join, e->side));
+    e->bc_inflight = true;
+    return GPE_OK;
+}
+static int bc_join(gpe_engine* e) {
+    if (e->bc_inflight && e->side) HIPCHK(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));
+    return GPE_OK;
+}
+static int launch_tail(gpe_engine* e, bool add_bc) {
+    const float* add = (add_bc && e->bc_inflight) ? e->grad_bc : nullptr;
+    hipLaunchKernelGGL(k_tail, dim3(add ? cdiv(e->P, 256) : 1), dim3(256), 0, e->stream, e->grad, add, e->P, e->dsc());
     HIPCHK(e, hipGetLastError());
-    if (with_backward) return mlp_backward(e, e->bc);
+    e->bc_inflight = false;
     return GPE_OK;
 }
 
@@ -861,9 +960,8 @@ int gpe_step_backward(gpe_engine* e) {
         HIPCHK(e, hipGetLastError());
         if ((rc = mlp_backward(e, e->sym))) return rc;
     }
-    if ((rc = bc_terms(e, true))) return rc;
-    hipLaunchKernelGGL(k_tail, dim3(1), dim3(1), 0, e->stream, e->grad + e->P, e->dsc());
-    HIPCHK(e, hipGetLastError());
+    if ((rc = bc_join(e))) return rc;
+    if ((rc = launch_tail(e, true))) return rc;
     e->phase = 2;
     return GPE_OK;
 }
@@ -895,15 +993,13 @@ int gpe_mse_begin(gpe_engine* e) {
     if (!e->mse_target || e->mse.n <= 0) FAIL(e, GPE_ERR_STATE, "mse step before bind_target");
     int rc;
     e->mse.x = e->main.x;
-    HIPCHK(e, hipMemsetAsync(e->dbl, 0, (S_COUNT + LS_COUNT + 4) * sizeof(double), e->stream));
-    HIPCHK(e, hipMemsetAsync(e->grad, 0, ((size_t)e->P + GT_COUNT) * sizeof(float), e->stream));
+    if ((rc = launch_begin(e))) return rc;
     if ((rc = mlp_forward(e, e->mse, true))) return rc;
     hipLaunchKernelGGL(k_seed_mse, dim3(head_grid(e, e->mse.n)), dim3(256), 0, e->stream, e->ph, e->mse.x, e->mse_target,
                        e->mse.O, e->mse.Ob, e->dsc() + 2, e->mse.n, e->mse.ld);
     HIPCHK(e, hipGetLastError());
     if ((rc = mlp_backward(e, e->mse))) return rc;
-    hipLaunchKernelGGL(k_tail, dim3(1), dim3(1), 0, e->stream, e->grad + e->P, e->dsc());
-    HIPCHK(e, hipGetLastError());
+    if ((rc = launch_tail(e, false))) return rc;
     e->phase = 3;
     return GPE_OK;
 }
@@ -981,7 +1077,64 @@ int gpe_step(gpe_engine* e, gpe_scalars* out) {
     return GPE_OK;
 }
 
+// Everything a captured step bakes into its kernel nodes: physics and optimiser constants, batch geometry and pointers.
+static std::vector<char> graph_key_of(gpe_engine* e) {
+    std::vector<char> k;
+    auto put = [&](const void* p, size_t n) { const char* c = (const char*)p; k.insert(k.end(), c, c + n); };
+    put(&e->ph, sizeof e->ph); put(&e->oc, sizeof e->oc); put(&e->base_norm, sizeof e->base_norm);
+    for (Batch* b : {&e->main, &e->bc, &e->sym}) {
+        const void* ptrs[] = {b->x, b->V, b->O, b->Ob, b->u, b->Hu, b->ux, b->stored, b->A0, b->A1};
+        put(ptrs, sizeof ptrs); put(&b->n, sizeof b->n); put(&b->C, sizeof b->C);
+    }
+    const void* more[] = {e->bc_target, e->grad, e->dbl, e->stream};
+    put(more, sizeof more); put(e->orth_host, sizeof e->orth_host);
+    put(&e->cfg.w_bc, sizeof e->cfg.w_bc); put(&e->cfg.w_sym, sizeof e->cfg.w_sym);
+    return k;
+}
+
+static void graph_drop(gpe_engine* e) {
+    if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
+    e->graph_key.clear();
+}
+
+// capture begin + backward + update on the private capture stream (the caller's stream may be the legacy null stream, which
+// cannot be captured); the instantiated graph is launched on the caller's stream.
+static int graph_build(gpe_engine* e) {
+    graph_drop(e);
+    if (!e->cap_stream && hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking) != hipSuccess) return GPE_ERR_HIP;
+    std::vector<char> key = graph_key_of(e);
+    hipStream_t s0 = e->stream;
+    e->stream = e->cap_stream;
+    e->packed_dirty = true;                       // every replayed step starts from freshly updated parameters
+    hipGraph_t g = nullptr;
+    int rc = GPE_OK;
+    if (hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { e->stream = s0; return GPE_ERR_HIP; }
+    if (!(rc = gpe_step_begin(e)) && !(rc = gpe_step_backward(e))) rc = gpe_step_update(e);
+    hipError_t st = hipStreamEndCapture(e->cap_stream, &g);
+    e->stream = s0;
+    e->phase = 0;
+    e->packed_dirty = true;
+    if (rc || st != hipSuccess || !g) { if (g) (void)hipGraphDestroy(g); (void)hipGetLastError(); return rc ? rc : GPE_ERR_HIP; }
+    st = hipGraphInstantiate(&e->graph_exec, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (st != hipSuccess) { e->graph_exec = nullptr; (void)hipGetLastError(); return GPE_ERR_HIP; }
+    e->graph_key.swap(key);
+    return GPE_OK;
+}
+
 int gpe_run(gpe_engine* e, int64_t n_steps) {
+    if (!e) return GPE_ERR_INVALID;
+    if (e->use_graph && !e->prof && n_steps >= 8 && e->main.n > 0) {
+        if (!e->graph_exec || e->graph_key != graph_key_of(e)) {
+            if (graph_build(e) != GPE_OK) { graph_drop(e); e->use_graph = false; }     // fall back to plain launches for good
+        }
+        if (e->graph_exec) {
+            for (int64_t i = 0; i < n_steps; ++i) HIPCHK(e, hipGraphLaunch(e->graph_exec, e->stream));
+            e->packed_dirty = true;
+            e->phase = 0;
+            return GPE_OK;
+        }
+    }
     for (int64_t i = 0; i < n_steps; ++i) {
         int rc = gpe_step(e, nullptr);
         if (rc) return rc;
@@ -993,8 +1146,7 @@ int gpe_residual(gpe_engine* e, gpe_scalars* out, float* d_psi, float* d_resid) 
     if (!e || !out) return GPE_ERR_INVALID;
     if (e->main.n <= 0) FAIL(e, GPE_ERR_STATE, "residual before bind_points");
     int rc;
-    HIPCHK(e, hipMemsetAsync(e->dbl, 0, (S_COUNT + LS_COUNT + 4) * sizeof(double), e->stream));
-    HIPCHK(e, hipMemsetAsync(e->grad, 0, ((size_t)e->P + GT_COUNT) * sizeof(float), e->stream));
+    if ((rc = launch_begin(e))) return rc;
     if ((rc = mlp_forward(e, e->main, false))) return rc;
     if ((rc = launch_head_pde(e))) return rc;
     if (e->cfg.w_sym != 0.f) {
@@ -1003,10 +1155,11 @@ int gpe_residual(gpe_engine* e, gpe_scalars* out, float* d_psi, float* d_resid) 
                            e->main.n, e->sym.ld);
     }
     if ((rc = launch_seed_pde(e, d_resid, 0))) return rc;
-    if ((rc = bc_terms(e, false))) return rc;
+    if ((rc = bc_fork(e, false))) return rc;
+    if ((rc = bc_join(e))) return rc;
     if (d_psi) hipLaunchKernelGGL(k_copy_psi, dim3(cdiv(e->main.n, 256)), dim3(256), 0, e->stream, e->main.u, d_psi, e->main.n,
                                   e->main.ld, e->nd.n_out);
-    hipLaunchKernelGGL(k_tail, dim3(1), dim3(1), 0, e->stream, e->grad + e->P, e->dsc());
+    if ((rc = launch_tail(e, false))) return rc;
     hipLaunchKernelGGL(k_update, dim3(1), dim3(1024), 0, e->stream, e->P, e->theta, e->am, e->av, e->grad, e->sums(),
                        e->lsums(), e->ph, e->oc, e->od, e->hist, e->cap, e->last, bc_count(e), 0, 0);
     HIPCHK(e, hipGetLastError());

@@ -76,13 +76,10 @@ GPE_DEV void tiles_transpose(const f32x4 (&v)[C], f32x4 (&o)[C], float* T, int m
 // pack hidden-hidden weights (linear maps 1..L-1) in MFMA fragment order.
 //   Wpk [j-1][nt][kt][lane][s] = W_j[16nt + (lane&15)][16kt + 4(lane>>4) + s]      (forward A operand)
 //   WpkT[j-1][kt][nt][lane][s] = W_j[16nt + 4(lane>>4) + s][16kt + (lane&15)]      (backward A operand)
-__global__ void k_pack_weights(NetDesc nd, int H, const float* __restrict__ theta, float* __restrict__ Wpk,
-                               float* __restrict__ WpkT) {
+GPE_DEV void pack_weight_element(const NetDesc& nd, int H, const float* __restrict__ theta, float* __restrict__ Wpk,
+                                 float* __restrict__ WpkT, int idx) {
     const int NT = H / 16;
-    const int L = nd.n_lin - 1;
-    int idx = blockIdx.x * 256 + threadIdx.x;
     int per = H * H;
-    if (idx >= (L - 1) * per) return;
     int j = idx / per + 1, e = idx % per;
     int s = e & 3, lane = (e >> 2) & 63, t2 = e >> 8;   // t2 = nt*NT+kt (or kt*NT+nt)
     int a = t2 / NT, b = t2 % NT;
@@ -90,6 +87,22 @@ __global__ void k_pack_weights(NetDesc nd, int H, const float* __restrict__ thet
     const float* W = theta + nd.offW[j];
     Wpk[idx] = W[(16 * a + i) * H + 16 * b + 4 * q + s];           // a = nt, b = kt
     WpkT[idx] = W[(16 * b + 4 * q + s) * H + 16 * a + i];          // a = kt, b = nt
+}
+__global__ void k_pack_weights(NetDesc nd, int H, const float* __restrict__ theta, float* __restrict__ Wpk,
+                               float* __restrict__ WpkT) {
+    int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < (nd.n_lin - 2) * H * H) pack_weight_element(nd, H, theta, Wpk, WpkT, idx);
+}
+// First kernel of a step: zero the step's accumulators (double sums, gradient + exchange tail, boundary-batch gradient) and,
+// on the fused path after a parameter update, repack the hidden-hidden weights -- one launch instead of three fills + a pack.
+__global__ void k_begin(NetDesc nd, int H, const float* __restrict__ theta, float* __restrict__ Wpk, float* __restrict__ WpkT,
+                        int n_pack, double* __restrict__ dbl, int n_dbl, float* __restrict__ grad, int n_grad,
+                        float* __restrict__ grad_bc, int n_bc) {
+    int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < n_pack) pack_weight_element(nd, H, theta, Wpk, WpkT, idx);
+    if (idx < n_dbl) dbl[idx] = 0.0;
+    if (idx < n_grad) grad[idx] = 0.f;
+    if (idx < n_bc) grad_bc[idx] = 0.f;
 }
 
 // ---- layer 0 helpers ---------------------------------------------------------------------------------------------
