@@ -57,6 +57,46 @@ GPE_DEV float row_sum16(float v) {
     return v;
 }
 
+// 16 values per lane, 16 lanes per DPP row: lane m of every row returns sum_{lanes of the row} v[m] -- a butterfly that
+// halves the live values each step (row_mirror, row_half_mirror, quad xor 2, quad xor 1): 30 DPP adds + 15 selects for what
+// 16 row_sum16 calls did in 64 DPP adds, and the 16 sums land on 16 different lanes, so ONE LDS atomic instruction (64 distinct
+// addresses) replaces 16 four-lane ones (ds_add_f32 costs ~100 cycles of the wave whatever the lane count).
+GPE_DEV float row_reduce_pick16(const float (&v)[16], int m) {
+    const bool b3 = (m & 8) != 0, b2 = (m & 4) != 0, b1 = (m & 2) != 0, b0 = (m & 1) != 0;
+    float a8[8], a4[4], a2[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float lo = v[i] + dpp_mov<0x140>(v[i]), hi = v[i + 8] + dpp_mov<0x140>(v[i + 8]);
+        a8[i] = b3 ? hi : lo;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float lo = a8[i] + dpp_mov<0x141>(a8[i]), hi = a8[i + 4] + dpp_mov<0x141>(a8[i + 4]);
+        a4[i] = b2 ? hi : lo;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float lo = a4[i] + dpp_mov<0x4E>(a4[i]), hi = a4[i + 2] + dpp_mov<0x4E>(a4[i + 2]);
+        a2[i] = b1 ? hi : lo;
+    }
+    const float lo = a2[0] + dpp_mov<0xB1>(a2[0]), hi = a2[1] + dpp_mov<0xB1>(a2[1]);
+    return b0 ? hi : lo;
+}
+// NF (= H/4) per-lane values, value f belonging to feature 16(f>>2) + 4q + (f&3): add their sums over the tile's 16 points to
+// dst[feature * stride]; chunks of 16 values, one atomic instruction per chunk.
+template <int NF>
+GPE_DEV void row_reduce_add(const float (&v)[NF], float* dst, int stride, int m, int q) {
+#pragma unroll
+    for (int f0 = 0; f0 < NF; f0 += 16) {
+        float c[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c[i] = (f0 + i < NF) ? v[(f0 + i < NF) ? f0 + i : 0] : 0.f;
+        const float t = row_reduce_pick16(c, m);
+        const int fi = f0 + m;
+        if (fi < NF) atomicAdd(&dst[(16 * (fi >> 2) + 4 * q + (fi & 3)) * stride], t);
+    }
+}
+
 // tile held point-on-lane (lane (m,q) reg r <-> row 4q+r, col m)  ->  feature-on-lane
 // (lane (i,q') element s <-> row i, col 4q'+s)
 // C tiles at once through C wave-private LDS tiles: one fence pair per batch instead of per tile.
@@ -387,6 +427,7 @@ __global__ __launch_bounds__((NHH > 0 ? 256 : (WLDS ? 512 : 256)), ((NHH > 0 || 
         // ---- output layer: dWout, dbout, adjoint into the last hidden layer, activation adjoint --------
         float zb[C][NF];
         {
+            float gwo[NOUT][NF];                  // per-point contributions to dW_out, reduced over the tile afterwards
             f32x4 stn[C];
             load_st(L - 1, 0, stn);
 #pragma unroll
@@ -398,7 +439,6 @@ __global__ __launch_bounds__((NHH > 0 ? 256 : (WLDS ? 512 : 256)), ((NHH > 0 || 
                 f32x4 wo[NOUT];
 #pragma unroll
                 for (int o = 0; o < NOUT; ++o) wo[o] = *reinterpret_cast<const f32x4*>(&Wo[o * H + 16 * nt + 4 * q]);
-                float gw[NOUT][4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float zk[D > 0 ? D : 1], zkk[D > 0 ? D : 1], a[C], ab[C], zv[C];
@@ -410,7 +450,7 @@ __global__ __launch_bounds__((NHH > 0 ? 256 : (WLDS ? 512 : 256)), ((NHH > 0 || 
                         float g = 0.f;
 #pragma unroll
                         for (int c = 0; c < C; ++c) g = fmaf(ob[o][c], a[c], g);
-                        gw[o][r] = row_sum16(g);
+                        gwo[o][nt * 4 + r] = g;
                     }
 #pragma unroll
                     for (int c = 0; c < C; ++c) {
@@ -423,13 +463,9 @@ __global__ __launch_bounds__((NHH > 0 ? 256 : (WLDS ? 512 : 256)), ((NHH > 0 || 
 #pragma unroll
                     for (int c = 0; c < C; ++c) zb[c][nt * 4 + r] = zv[c];
                 }
-                if (m == 0) {
-#pragma unroll
-                    for (int o = 0; o < NOUT; ++o)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) atomicAdd(&gacc[nd.offW[L] + o * H + 16 * nt + 4 * q + r], gw[o][r]);
-                }
             }
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) row_reduce_add<NF>(gwo[o], &gacc[nd.offW[L] + o * H], 1, m, q);
             float gbo[NOUT];
 #pragma unroll
             for (int o = 0; o < NOUT; ++o) gbo[o] = row_sum16(ob[o][0]);
@@ -444,15 +480,7 @@ __global__ __launch_bounds__((NHH > 0 ? 256 : (WLDS ? 512 : 256)), ((NHH > 0 || 
 #pragma unroll
         for (int j = jtop; j >= 1; --j) {
             // bias gradient of map j
-            {
-                float gb[NF];
-#pragma unroll
-                for (int f = 0; f < NF; ++f) gb[f] = row_sum16(zb[0][f]);
-                if (m == 0) {
-#pragma unroll
-                    for (int f = 0; f < NF; ++f) atomicAdd(&gacc[nd.offB[j] + 16 * (f >> 2) + 4 * q + (f & 3)], gb[f]);
-                }
-            }
+            row_reduce_add<NF>(zb[0], &gacc[nd.offB[j]], 1, m, q);
             // ---- (1) transpose Zb once: C*NT tiles, kept in registers for the weight-gradient products ------------
             STAMP(1);
             f32x4 zt[NT][C];
@@ -560,26 +588,18 @@ __global__ __launch_bounds__((NHH > 0 ? 256 : (WLDS ? 512 : 256)), ((NHH > 0 || 
                 }
             }
         }
-        // ---- linear map 0: z = W0 x + b0, dz/dx_k = W0[:,k]  ->  padded LDS area g0[n][4] = (dW0[n][0..2], db0[n]) -------
+        // ---- linear map 0: z = W0 x + b0, dz/dx_k = W0[:,k]  ->  LDS area g0[4][H] = (dW0[:, 0..2], db0) ------------------------
+        row_reduce_add<NF>(zb[0], &g0[3 * H], 1, m, q);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            float g[4][4];
+        for (int k = 0; k < 3; ++k) {
+            if (k < D || (D == 0 && k < dim)) {
+                float v[NF];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int f = nt * 4 + r;
-                g[r][3] = row_sum16(zb[0][f]);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    float v = zb[0][f] * xv[k];
-                    if constexpr (C > 1) { if (k < D) v += zb[(1 + k) < C ? (1 + k) : 0][f]; }
-                    g[r][k] = row_sum16(v);
+                for (int f = 0; f < NF; ++f) {
+                    v[f] = zb[0][f] * xv[k];
+                    if constexpr (C > 1) { if (k < D) v[f] += zb[(1 + k) < C ? (1 + k) : 0][f]; }
                 }
-            }
-            if (m == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) atomicAdd(&g0[(16 * nt + 4 * q + r) * 4 + k], g[r][k]);
+                row_reduce_add<NF>(v, &g0[k * H], 1, m, q);
             }
         }
         STAMP(6);
@@ -603,7 +623,7 @@ __global__ __launch_bounds__((NHH > 0 ? 256 : (WLDS ? 512 : 256)), ((NHH > 0 || 
     __syncthreads();
     if constexpr (GACC) {                               // only the padded layer-0 block lives in LDS
         for (int i = threadIdx.x; i < 4 * H; i += NTHR) {
-            const int n = i >> 2, k = i & 3;
+            const int n = i % H, k = i / H;
             if (k == 3) atomicAdd(&gacc[nd.offB[0] + n], g0[i]);
             else if (k < dim) atomicAdd(&gacc[nd.offW[0] + n * dim + k], g0[i]);
         }
@@ -624,7 +644,7 @@ __global__ __launch_bounds__((NHH > 0 ? 256 : (WLDS ? 512 : 256)), ((NHH > 0 || 
         slab[i] = gacc[src];
     }
     for (int i = threadIdx.x; i < 4 * H; i += NTHR) {
-        const int n = i >> 2, k = i & 3;
+        const int n = i % H, k = i / H;
         if (k == 3) slab[nd.offB[0] + n] = g0[i];
         else if (k < dim) slab[nd.offW[0] + n * dim + k] = g0[i];
     }
