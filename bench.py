@@ -171,6 +171,11 @@ def main():
     if rank == 0:
         flops_pt, bmat_pt = eng.step_cost()
         f_fwd = flops_pt / 3.0
+        # channels the training batches carry: value, d first derivatives, ONE Laplacian channel (SURVEY 8(d) counts 1 + 2d;
+        # its per-point figure is reported next to the executed one -- the roofline fraction uses only executed flops)
+        d_in, Hh, Lh = layers[0], layers[1], len(layers) - 2
+        chan = d_in + 2
+        survey_fwd = 2.0 * d_in * Hh + (1 + 2 * d_in) * (2.0 * Hh * Hh * (Lh - 1) + 2.0 * Hh * layers[-1]) + Hh * Lh * (3 + 5 * d_in)
         pts = n_local * world * args.steps
         value = pts / elapsed
         bwd_s = prof["bwd_ms"] / max(1, prof["bwd_launches"]) * 1e-3
@@ -200,15 +205,16 @@ def main():
                        "parallelism": f"dp{world}", "kernel_path": "fused_mfma_f32_16x16x4"},
             "per_gpu_points_per_s": value / world,
             "final_loss": sc["loss"], "final_mu": sc["mu"],
-            "roofline": {"bound": "mfma", "kernel": "f_backward<%d,%d,1> (fused jet reverse pass)" % (layers[1], 1 + 2 * layers[0]),
+            "roofline": {"bound": "mfma", "kernel": "f_backward<%d,%d,1> (fused jet reverse pass, %d channels)" % (layers[1], chan, chan),
                          "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
-                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": (bmat_pt / 2.0 * (len(layers) - 3) / (len(layers) - 2) + 4.0 * (1 + 2 * layers[0]) + 4.0 * layers[0] + 8.0) * n_local,
+                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": (bmat_pt / 2.0 * (len(layers) - 3) / (len(layers) - 2) + 4.0 * chan + 4.0 * layers[0] + 8.0) * n_local,
                          "algorithmic_flop_per_point": 2.0 * f_fwd, "avg_launch_ms": bwd_s * 1e3,
                          "launches": prof["bwd_launches"]},
-            "roofline_forward": {"bound": "mfma", "kernel": "f_forward<%d,%d,1>" % (layers[1], 1 + 2 * layers[0]), "achieved": ach_f,
+            "roofline_forward": {"bound": "mfma", "kernel": "f_forward<%d,%d,1>" % (layers[1], chan), "achieved": ach_f,
                                  "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_f / FP32_MFMA_PEAK_TFLOPS,
                                  "algorithmic_flop_per_point": f_fwd, "avg_launch_ms": fwd_s * 1e3},
+            "jet_channels": chan, "survey_8d_step_flop_per_point": 3.0 * survey_fwd,
             "step_flop_per_point": flops_pt, "whole_step_tflops": flops_pt * value / world / 1e12,
             "b_mat_bytes_per_point": bmat_pt, "b_mat_gbps": bmat_pt * value / world / 1e9,
         }

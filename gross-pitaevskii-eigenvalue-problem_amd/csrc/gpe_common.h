@@ -84,16 +84,30 @@ GPE_DEV float gpe_tanh(float x) {
     return ax < 0.25f ? p : r;
 }
 
+// Jet channels.  A batch carries C = 1 + D + E channels per feature: the value, D first derivatives and E second-order
+// channels.  E = D ("full"): the diagonal second derivatives d2/dx_k^2 one by one.  E = 1 with D > 1 ("Laplacian"): only their
+// SUM -- every map of the network is linear in the second-order channels and the physics needs nothing but the Laplacian
+// (k_head_pde), so the training batches propagate one summed channel: 4 channels instead of 5 in 2D, 5 instead of 7 in 3D.
+//
 // activation jets:  a = t + shift, a_k = s z_k, a_kk = s z_kk - 2 t s z_k^2   (t = tanh z, s = 1 - t^2)
-template <int D>
-GPE_DEV void act_from_stored(float t, const float* zk, const float* zkk, float shift, float* a /*[1+2D]*/) {
+//                   Laplacian channel: a_L = s z_L - 2 t s sum_k z_k^2
+template <int D, int E>
+GPE_DEV void act_from_stored(float t, const float* zk, const float* zkk, float shift, float* a /*[1+D+E]*/) {
     float s = fmaf(-t, t, 1.0f);
     a[0] = t + shift;
     float ts2 = 2.0f * t * s;
+    if constexpr (E == D) {
 #pragma unroll
-    for (int j = 0; j < D; ++j) {
-        a[1 + j] = s * zk[j];
-        a[1 + D + j] = fmaf(s, zkk[j], -ts2 * zk[j] * zk[j]);
+        for (int j = 0; j < D; ++j) {
+            a[1 + j] = s * zk[j];
+            a[1 + D + j] = fmaf(s, zkk[j], -ts2 * zk[j] * zk[j]);
+        }
+    } else {
+        static_assert(E == 1, "second-order channels: one per axis, or the single Laplacian channel");
+        float S = 0.f;
+#pragma unroll
+        for (int j = 0; j < D; ++j) { a[1 + j] = s * zk[j]; S = fmaf(zk[j], zk[j], S); }
+        a[1 + D] = fmaf(s, zkk[0], -ts2 * S);
     }
 }
 
@@ -101,19 +115,35 @@ GPE_DEV void act_from_stored(float t, const float* zk, const float* zkk, float s
 //   zbar_kk = s abar_kk
 //   zbar_k  = s abar_k - 4 t s z_k abar_kk
 //   zbar    = s abar + sum_k [ (-2ts) z_k abar_k + ((-2ts) z_kk + (-2s^2+4t^2 s) z_k^2) abar_kk ]
-template <int D>
-GPE_DEV void act_adjoint(float t, const float* zk, const float* zkk, const float* ab /*[1+2D]*/, float* zb /*[1+2D]*/) {
+// Laplacian channel: the same with abar_kk -> abar_L for every k, z_kk -> z_L once, z_k^2 -> sum_k z_k^2.
+template <int D, int E>
+GPE_DEV void act_adjoint(float t, const float* zk, const float* zkk, const float* ab /*[1+D+E]*/, float* zb /*[1+D+E]*/) {
     float s = fmaf(-t, t, 1.0f);
     float m2ts = -2.0f * t * s;
     float q = s * (4.0f * t * t - 2.0f * s);
     float acc = s * ab[0];
+    if constexpr (E == D) {
 #pragma unroll
-    for (int j = 0; j < D; ++j) {
-        float akb = ab[1 + j], akkb = ab[1 + D + j];
-        zb[1 + D + j] = s * akkb;
-        zb[1 + j] = fmaf(s, akb, 2.0f * m2ts * zk[j] * akkb);
-        acc = fmaf(m2ts * zk[j], akb, acc);
-        acc = fmaf(fmaf(m2ts, zkk[j], q * zk[j] * zk[j]), akkb, acc);
+        for (int j = 0; j < D; ++j) {
+            float akb = ab[1 + j], akkb = ab[1 + D + j];
+            zb[1 + D + j] = s * akkb;
+            zb[1 + j] = fmaf(s, akb, 2.0f * m2ts * zk[j] * akkb);
+            acc = fmaf(m2ts * zk[j], akb, acc);
+            acc = fmaf(fmaf(m2ts, zkk[j], q * zk[j] * zk[j]), akkb, acc);
+        }
+    } else {
+        static_assert(E == 1, "second-order channels: one per axis, or the single Laplacian channel");
+        const float aLb = ab[1 + D];
+        zb[1 + D] = s * aLb;
+        float S = 0.f;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            float akb = ab[1 + j];
+            zb[1 + j] = fmaf(s, akb, 2.0f * m2ts * zk[j] * aLb);
+            acc = fmaf(m2ts * zk[j], akb, acc);
+            S = fmaf(zk[j], zk[j], S);
+        }
+        acc = fmaf(fmaf(m2ts, zkk[0], q * S), aLb, acc);
     }
     zb[0] = acc;
 }

@@ -165,7 +165,7 @@ struct Batch {
     const float* x = nullptr;      // [n][dim]
     const float* V = nullptr;
     int64_t n = 0, ld = 0;
-    int C = 1;
+    int C = 1, E = 0;              // channels: 1 value + D first derivatives + E second-order channels (gpe_common.h)
     float* O = nullptr;            // [C][n_out][ld]
     float* Ob = nullptr;
     float* u = nullptr;            // [n_out][ld]  (main batch)
@@ -244,14 +244,14 @@ static int dev_alloc(gpe_engine* e, Batch* b, T** out, size_t count) {
     return GPE_OK;
 }
 
-static int setup_batch(gpe_engine* e, Batch& b, const float* x, int64_t n, int C, bool with_head, const float* V,
+static int setup_batch(gpe_engine* e, Batch& b, const float* x, int64_t n, int C, int E, bool with_head, const float* V,
                        bool with_store = true) {
-    if (b.n == n && b.C == C && b.O) { b.x = x; b.V = V; return GPE_OK; }
+    if (b.n == n && b.C == C && b.E == E && b.O) { b.x = x; b.V = V; return GPE_OK; }
     HIPCHK(e, hipStreamSynchronize(e->stream));
     float* keep_xown = nullptr;
     (void)keep_xown;
     free_batch(b);
-    b.x = x; b.V = V; b.n = n; b.C = C;
+    b.x = x; b.V = V; b.n = n; b.C = C; b.E = E;
     b.ld = round_up(n, 64);
     const int no = e->nd.n_out;
     int rc;
@@ -282,25 +282,47 @@ static int setup_batch(gpe_engine* e, Batch& b, const float* x, int64_t n, int C
 }
 
 // ---- MLP forward / backward dispatch ---------------------------------------------------------------
-#define DISPATCH_C(Cv, ...)                                           \
-    switch (Cv) {                                                     \
-        case 1: { constexpr int CC = 1; __VA_ARGS__; } break;         \
-        case 3: { constexpr int CC = 3; __VA_ARGS__; } break;         \
-        case 5: { constexpr int CC = 5; __VA_ARGS__; } break;         \
-        case 7: { constexpr int CC = 7; __VA_ARGS__; } break;         \
-        default: FAIL(e, GPE_ERR_INVALID, "bad channel count %d", Cv); \
+// (C, E) pairs that exist: value only (1,0); 1D (3,1); Laplacian-channel training batches 2D (4,1), 3D (5,1); full diagonal
+// second derivatives for gpe_forward_jets 2D (5,2), 3D (7,3) -- forward kernels only.
+#define CE_CASE(Cc, Ee, ...) case (Cc) * 10 + (Ee): { constexpr int CC = Cc; constexpr int EE = Ee; __VA_ARGS__; } break;
+#ifdef GPE_FAST_BUILD    // kernel-tuning builds (tools/build_variant.sh): only what the 2D n_out = 1, H = 64 workloads launch
+#define DISPATCH_TRAIN(bb, ...)                                        \
+    switch ((bb).C * 10 + (bb).E) {                                    \
+        CE_CASE(1, 0, __VA_ARGS__) CE_CASE(4, 1, __VA_ARGS__)          \
+        default: FAIL(e, GPE_ERR_INVALID, "fast build: channels (%d,%d) not compiled", (bb).C, (bb).E); \
     }
+#define DISPATCH_FWD(bb, ...) DISPATCH_TRAIN(bb, __VA_ARGS__)
+#else
+#define DISPATCH_TRAIN(bb, ...)                                        \
+    switch ((bb).C * 10 + (bb).E) {                                    \
+        CE_CASE(1, 0, __VA_ARGS__) CE_CASE(3, 1, __VA_ARGS__) CE_CASE(4, 1, __VA_ARGS__) CE_CASE(5, 1, __VA_ARGS__) \
+        default: FAIL(e, GPE_ERR_INVALID, "bad channel pair (%d,%d)", (bb).C, (bb).E); \
+    }
+#define DISPATCH_FWD(bb, ...)                                          \
+    switch ((bb).C * 10 + (bb).E) {                                    \
+        CE_CASE(1, 0, __VA_ARGS__) CE_CASE(3, 1, __VA_ARGS__) CE_CASE(4, 1, __VA_ARGS__) CE_CASE(5, 1, __VA_ARGS__) \
+        CE_CASE(5, 2, __VA_ARGS__) CE_CASE(7, 3, __VA_ARGS__)          \
+        default: FAIL(e, GPE_ERR_INVALID, "bad channel pair (%d,%d)", (bb).C, (bb).E); \
+    }
+#endif
 
-#define F_LAUNCH(KERNEL, HH, CC, WL, GRID, BLOCK, LDS, ...)                                                    \
+#ifdef GPE_FAST_BUILD
+#define F_LAUNCH(KERNEL, HH, CC, EE, WL, GRID, BLOCK, LDS, ...) \
+    hipLaunchKernelGGL((KERNEL<HH, CC, EE, 1, WL>), dim3(GRID), dim3(BLOCK), LDS, e->stream, __VA_ARGS__)
+#define B_LAUNCH(HH, CC, EE, WL, NH, GRID, BLOCK, LDS, ...) \
+    hipLaunchKernelGGL((f_backward<HH, CC, EE, 1, WL, NH>), dim3(GRID), dim3(BLOCK), LDS, e->stream, __VA_ARGS__)
+#else
+#define F_LAUNCH(KERNEL, HH, CC, EE, WL, GRID, BLOCK, LDS, ...)                                                    \
     do {                                                                                                         \
-        if (e->nd.n_out == 1) hipLaunchKernelGGL((KERNEL<HH, CC, 1, WL>), dim3(GRID), dim3(BLOCK), LDS, e->stream, __VA_ARGS__); \
-        else                  hipLaunchKernelGGL((KERNEL<HH, CC, 2, WL>), dim3(GRID), dim3(BLOCK), LDS, e->stream, __VA_ARGS__); \
+        if (e->nd.n_out == 1) hipLaunchKernelGGL((KERNEL<HH, CC, EE, 1, WL>), dim3(GRID), dim3(BLOCK), LDS, e->stream, __VA_ARGS__); \
+        else                  hipLaunchKernelGGL((KERNEL<HH, CC, EE, 2, WL>), dim3(GRID), dim3(BLOCK), LDS, e->stream, __VA_ARGS__); \
     } while (0)
-#define B_LAUNCH(HH, CC, WL, NH, GRID, BLOCK, LDS, ...)                                                        \
+#define B_LAUNCH(HH, CC, EE, WL, NH, GRID, BLOCK, LDS, ...)                                                        \
     do {                                                                                                         \
-        if (e->nd.n_out == 1) hipLaunchKernelGGL((f_backward<HH, CC, 1, WL, NH>), dim3(GRID), dim3(BLOCK), LDS, e->stream, __VA_ARGS__); \
-        else                  hipLaunchKernelGGL((f_backward<HH, CC, 2, WL, NH>), dim3(GRID), dim3(BLOCK), LDS, e->stream, __VA_ARGS__); \
+        if (e->nd.n_out == 1) hipLaunchKernelGGL((f_backward<HH, CC, EE, 1, WL, NH>), dim3(GRID), dim3(BLOCK), LDS, e->stream, __VA_ARGS__); \
+        else                  hipLaunchKernelGGL((f_backward<HH, CC, EE, 2, WL, NH>), dim3(GRID), dim3(BLOCK), LDS, e->stream, __VA_ARGS__); \
     } while (0)
+#endif
 
 static size_t fused_w_bytes(gpe_engine* e) { return (size_t)(e->nd.n_lin - 2) * e->H * e->H * sizeof(float); }
 static size_t fused_small_bytes(gpe_engine* e) {       // = small_count() of gpe_fused.h, rounded up to 16 bytes
@@ -310,16 +332,16 @@ static size_t fused_small_bytes(gpe_engine* e) {       // = small_count() of gpe
 static bool staged_batch(gpe_engine* e, const Batch& b) { return (b.n + 15) / 16 >= e->stage_min_tiles; }
 static size_t fused_fwd_lds(gpe_engine* e, bool staged) { return fused_small_bytes(e) + (e->fwd_wlds && staged ? fused_w_bytes(e) : 0); }
 
-template <int HH, int CC>
+template <int HH, int CC, int EE>
 static void launch_f_forward(gpe_engine* e, Batch& b, unsigned grid, int store) {
     if constexpr (HH > 64) {
-        F_LAUNCH(f_forward, HH, CC, false, grid, 256, fused_fwd_lds(e, false), e->nd, e->theta, e->Wpk, b.x, b.stored, b.O, b.n, b.ld, store);
+        F_LAUNCH(f_forward, HH, CC, EE, false, grid, 256, fused_fwd_lds(e, false), e->nd, e->theta, e->Wpk, b.x, b.stored, b.O, b.n, b.ld, store);
         return;
     }
     if (e->fwd_wlds && staged_batch(e, b))
-        F_LAUNCH(f_forward, HH, CC, true, grid, 256, fused_fwd_lds(e, true), e->nd, e->theta, e->Wpk, b.x, b.stored, b.O, b.n, b.ld, store);
+        F_LAUNCH(f_forward, HH, CC, EE, true, grid, 256, fused_fwd_lds(e, true), e->nd, e->theta, e->Wpk, b.x, b.stored, b.O, b.n, b.ld, store);
     else
-        F_LAUNCH(f_forward, HH, CC, false, grid, 256, fused_fwd_lds(e, false), e->nd, e->theta, e->Wpk, b.x, b.stored, b.O, b.n, b.ld, store);
+        F_LAUNCH(f_forward, HH, CC, EE, false, grid, 256, fused_fwd_lds(e, false), e->nd, e->theta, e->Wpk, b.x, b.stored, b.O, b.n, b.ld, store);
 }
 // reverse-kernel variant for one batch: 2 = weight gradients in registers (1 wave/SIMD), 1 = 512-thread LDS-weight variant,
 // 0 = plain (LDS-atomic gradients, weights from L2; also the fastest when every wave sees only a tile or two)
@@ -327,24 +349,24 @@ static int bwd_kind(gpe_engine* e, const Batch& b) {
     if (e->H > 64 || !staged_batch(e, b)) return 0;
     return e->bwd_racc ? 2 : (e->bwd_wlds ? 1 : 0);
 }
-template <int HH, int CC>
+template <int HH, int CC, int EE>
 static void launch_f_backward(gpe_engine* e, Batch& b, unsigned grid, size_t lds) {
     if constexpr (HH > 64) {
-        B_LAUNCH(HH, CC, false, 0, grid, 256, lds, e->nd, e->theta, e->WpkT, b.x, b.stored, b.Ob, e->gslab, b.n, b.ld, e->Ppad, e->nslab_g);
+        B_LAUNCH(HH, CC, EE, false, 0, grid, 256, lds, e->nd, e->theta, e->WpkT, b.x, b.stored, b.Ob, e->gslab, b.n, b.ld, e->Ppad, e->nslab_g);
         return;
     } else {
 #define BARGS e->nd, e->theta, e->WpkT, b.x, b.stored, b.Ob, e->gslab, b.n, b.ld, e->Ppad, e->nslab_g
     const int kind = bwd_kind(e, b);
     if (kind == 2) {
         switch (e->nd.n_lin - 2) {
-            case 1: B_LAUNCH(HH, CC, true, 1, grid, 256, lds, BARGS); break;
-            case 2: B_LAUNCH(HH, CC, true, 2, grid, 256, lds, BARGS); break;
-            default: B_LAUNCH(HH, CC, true, 3, grid, 256, lds, BARGS); break;
+            case 1: B_LAUNCH(HH, CC, EE, true, 1, grid, 256, lds, BARGS); break;
+            case 2: B_LAUNCH(HH, CC, EE, true, 2, grid, 256, lds, BARGS); break;
+            default: B_LAUNCH(HH, CC, EE, true, 3, grid, 256, lds, BARGS); break;
         }
     } else if (kind == 1)
-        B_LAUNCH(HH, CC, true, 0, grid, 512, lds, BARGS);
+        B_LAUNCH(HH, CC, EE, true, 0, grid, 512, lds, BARGS);
     else
-        B_LAUNCH(HH, CC, false, 0, grid, 256, lds, BARGS);
+        B_LAUNCH(HH, CC, EE, false, 0, grid, 256, lds, BARGS);
 #undef BARGS
     }
 }
@@ -414,16 +436,23 @@ static int mlp_forward(gpe_engine* e, Batch& b, bool store) {
         if (rc) return rc;
         unsigned grid = fused_grid(e, b.n, 4, 2);
         if (mark) prof_mark(e, 0, true);
+#ifdef GPE_FAST_BUILD
+        if (e->H != 64 || e->nd.n_out != 1) FAIL(e, GPE_ERR_INVALID, "fast build: only H = 64, n_out = 1 compiled");
+        DISPATCH_FWD(b, launch_f_forward<64, CC, EE>(e, b, grid, store ? 1 : 0));
+#else
         if (e->H == 128) {      // wide layers: one wave per SIMD, C <= 5 (checked at create)
             grid = fused_grid(e, b.n, 4, 1);
-            switch (b.C) {
-                case 1: launch_f_forward<128, 1>(e, b, grid, store ? 1 : 0); break;
-                case 3: launch_f_forward<128, 3>(e, b, grid, store ? 1 : 0); break;
-                default: launch_f_forward<128, 5>(e, b, grid, store ? 1 : 0); break;
+            switch (b.C * 10 + b.E) {     // wide layers: dim <= 2 (checked at create)
+                case 10: launch_f_forward<128, 1, 0>(e, b, grid, store ? 1 : 0); break;
+                case 31: launch_f_forward<128, 3, 1>(e, b, grid, store ? 1 : 0); break;
+                case 41: launch_f_forward<128, 4, 1>(e, b, grid, store ? 1 : 0); break;
+                case 52: launch_f_forward<128, 5, 2>(e, b, grid, store ? 1 : 0); break;
+                default: FAIL(e, GPE_ERR_INVALID, "bad channel pair (%d,%d) for H = 128", b.C, b.E);
             }
         }
-        else if (e->H == 64) { DISPATCH_C(b.C, launch_f_forward<64, CC>(e, b, grid, store ? 1 : 0)); }
-        else            { DISPATCH_C(b.C, launch_f_forward<32, CC>(e, b, grid, store ? 1 : 0)); }
+        else if (e->H == 64) { DISPATCH_FWD(b, launch_f_forward<64, CC, EE>(e, b, grid, store ? 1 : 0)); }
+        else            { DISPATCH_FWD(b, launch_f_forward<32, CC, EE>(e, b, grid, store ? 1 : 0)); }
+#endif
         if (mark) prof_mark(e, 0, false);
     } else {
         const NetDesc& nd = e->nd;
@@ -431,7 +460,7 @@ static int mlp_forward(gpe_engine* e, Batch& b, bool store) {
             const float* Sprev = lin > 0 ? b.S[lin - 1] : nullptr;
             float* Out = (lin == nd.n_lin - 1) ? b.O : b.S[lin];
             dim3 grid(cdiv(b.n, 256), cdiv(nd.width[lin + 1], G_FB));
-            DISPATCH_C(b.C, hipLaunchKernelGGL((g_fwd_layer<CC>), grid, dim3(256), 0, e->stream, nd, lin, e->theta, b.x,
+            DISPATCH_FWD(b, hipLaunchKernelGGL((g_fwd_layer<CC, EE>), grid, dim3(256), 0, e->stream, nd, lin, e->theta, b.x,
                                                 Sprev, Out, b.n, b.ld));
         }
     }
@@ -449,18 +478,24 @@ static int mlp_backward(gpe_engine* e, Batch& b) {
         const bool mark = e->prof && (&b == &e->main);
         if (mark) prof_mark(e, 1, true);
         int nred = (int)grid;
+#ifdef GPE_FAST_BUILD
+        if (e->H != 64 || e->nd.n_out != 1) FAIL(e, GPE_ERR_INVALID, "fast build: only H = 64, n_out = 1 compiled");
+        DISPATCH_TRAIN(b, launch_f_backward<64, CC, EE>(e, b, grid, lds));
+#else
         if (e->H == 128) {
             grid = fused_grid(e, b.n, 4, 1);
             nred = e->nslab_g;
             HIPCHK(e, hipMemsetAsync(e->gslab, 0, (size_t)e->nslab_g * e->Ppad * sizeof(float), e->stream));
-            switch (b.C) {
-                case 1: launch_f_backward<128, 1>(e, b, grid, lds); break;
-                case 3: launch_f_backward<128, 3>(e, b, grid, lds); break;
-                default: launch_f_backward<128, 5>(e, b, grid, lds); break;
+            switch (b.C * 10 + b.E) {
+                case 10: launch_f_backward<128, 1, 0>(e, b, grid, lds); break;
+                case 31: launch_f_backward<128, 3, 1>(e, b, grid, lds); break;
+                case 41: launch_f_backward<128, 4, 1>(e, b, grid, lds); break;
+                default: FAIL(e, GPE_ERR_INVALID, "bad channel pair (%d,%d) for H = 128", b.C, b.E);
             }
         }
-        else if (e->H == 64) { DISPATCH_C(b.C, launch_f_backward<64, CC>(e, b, grid, lds)); }
-        else            { DISPATCH_C(b.C, launch_f_backward<32, CC>(e, b, grid, lds)); }
+        else if (e->H == 64) { DISPATCH_TRAIN(b, launch_f_backward<64, CC, EE>(e, b, grid, lds)); }
+        else            { DISPATCH_TRAIN(b, launch_f_backward<32, CC, EE>(e, b, grid, lds)); }
+#endif
         if (mark) prof_mark(e, 1, false);
         HIPCHK(e, hipGetLastError());
         hipLaunchKernelGGL(k_grad_reduce, dim3(cdiv(e->P, 64)), dim3(1024), 0, e->stream, e->gslab, nred, e->Ppad,
@@ -473,14 +508,14 @@ static int mlp_backward(gpe_engine* e, Batch& b) {
             const int K = nd.width[lin], Ho = nd.width[lin + 1];
             const float* Sprev = lin > 0 ? b.S[lin - 1] : nullptr;
             dim3 gw(Ho, cdiv(K, G_KB));
-            DISPATCH_C(b.C, hipLaunchKernelGGL((g_bwd_weight<CC>), gw, dim3(256), 0, e->stream, nd, lin, b.x, Sprev, Zb,
+            DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_weight<CC, EE>), gw, dim3(256), 0, e->stream, nd, lin, b.x, Sprev, Zb,
                                                 e->grad, b.n, b.ld));
             if (lin > 0) {
                 dim3 gd(cdiv(b.n, 256), cdiv(K, G_FB));
-                DISPATCH_C(b.C, hipLaunchKernelGGL((g_bwd_data<CC>), gd, dim3(256), 0, e->stream, nd, lin, e->theta, Zb,
+                DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_data<CC>), gd, dim3(256), 0, e->stream, nd, lin, e->theta, Zb,
                                                     nxt, b.n, b.ld));
                 dim3 ga(cdiv(b.n, 256), K);
-                DISPATCH_C(b.C, hipLaunchKernelGGL((g_bwd_act<CC>), ga, dim3(256), 0, e->stream, K, Sprev, nxt, b.n, b.ld));
+                DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_act<CC, EE>), ga, dim3(256), 0, e->stream, K, Sprev, nxt, b.n, b.ld));
                 Zb = nxt;
                 nxt = (nxt == b.A0) ? b.A1 : b.A0;
             }
@@ -597,7 +632,7 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
     for (int i = 2; i < c.n_layers - 1; ++i) uniform = uniform && (c.layers[i] == c.layers[1]);
     const int H = c.layers[1];
     const int Lh = c.n_layers - 2;
-    size_t lds_need = ((size_t)e->Ppad + (size_t)(8 + c.n_layers + 2) * c.layers[1] + 8 + 4 * (1 + 2 * dim) * F_TILE) * sizeof(float);
+    size_t lds_need = ((size_t)e->Ppad + (size_t)(8 + c.n_layers + 2) * c.layers[1] + 8 + 4 * (dim + 2) * F_TILE) * sizeof(float);
     bool fused_ok = uniform && (H == 32 || H == 64) && Lh >= 2 && lds_need <= 160 * 1024;
     if (uniform && H == 128 && Lh >= 2 && dim <= 2) fused_ok = true;          // wide variant: global-atomic gradient slabs
     if (c.path == GPE_PATH_FUSED && !fused_ok)
@@ -628,7 +663,7 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
         ok = alloc((void**)&e->Wpk, (size_t)(Lh - 1) * H * H * 4) && alloc((void**)&e->WpkT, (size_t)(Lh - 1) * H * H * 4) &&
              alloc((void**)&e->gslab, (size_t)e->nslab * e->Ppad * 4);
         if (ok) {
-            const int Cmain = 1 + 2 * dim;
+            const int Cmain = dim + 2;        // training batches: value, dim first derivatives, Laplacian
             const size_t wb = (size_t)(Lh - 1) * H * H * sizeof(float);
             const char* env = getenv("GPE_WLDS");                     // tuning switch: 0 = weights from L2, 1 = from LDS
             const bool want = env ? (atoi(env) != 0) : true;
@@ -644,21 +679,25 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
                           ((size_t)e->Ppad + 4 * (size_t)H + 4 * (size_t)Cmain * F_TILE) * sizeof(float) + smallb + wb <= 160 * 1024;
             // allow > 64 KB dynamic LDS
             const int lds_b = 160 * 1024, lds_f = 64 * 1024;
-#define SETLDS(HH, CC, NO)                                                                                                   \
-    (void)hipFuncSetAttribute((const void*)f_backward<HH, CC, NO, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
-    (void)hipFuncSetAttribute((const void*)f_backward<HH, CC, NO, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);  \
-    (void)hipFuncSetAttribute((const void*)f_backward<HH, CC, NO, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);  \
-    (void)hipFuncSetAttribute((const void*)f_backward<HH, CC, NO, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);  \
-    (void)hipFuncSetAttribute((const void*)f_backward<HH, CC, NO, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);  \
-    (void)hipFuncSetAttribute((const void*)f_forward<HH, CC, NO, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_f)
-            SETLDS(64, 1, 1); SETLDS(64, 3, 1); SETLDS(64, 5, 1); SETLDS(64, 7, 1);
-            SETLDS(64, 1, 2); SETLDS(64, 3, 2); SETLDS(64, 5, 2); SETLDS(64, 7, 2);
-            SETLDS(32, 1, 1); SETLDS(32, 3, 1); SETLDS(32, 5, 1); SETLDS(32, 7, 1);
-            SETLDS(32, 1, 2); SETLDS(32, 3, 2); SETLDS(32, 5, 2); SETLDS(32, 7, 2);
+#define SETLDS(HH, CC, EE, NO)                                                                                                   \
+    (void)hipFuncSetAttribute((const void*)f_backward<HH, CC, EE, NO, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
+    (void)hipFuncSetAttribute((const void*)f_backward<HH, CC, EE, NO, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);  \
+    (void)hipFuncSetAttribute((const void*)f_backward<HH, CC, EE, NO, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);  \
+    (void)hipFuncSetAttribute((const void*)f_backward<HH, CC, EE, NO, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);  \
+    (void)hipFuncSetAttribute((const void*)f_backward<HH, CC, EE, NO, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);  \
+    (void)hipFuncSetAttribute((const void*)f_forward<HH, CC, EE, NO, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_f)
+#ifdef GPE_FAST_BUILD
+            SETLDS(64, 1, 0, 1); SETLDS(64, 4, 1, 1);
+#else
+            SETLDS(64, 1, 0, 1); SETLDS(64, 3, 1, 1); SETLDS(64, 4, 1, 1); SETLDS(64, 5, 1, 1);
+            SETLDS(64, 1, 0, 2); SETLDS(64, 3, 1, 2); SETLDS(64, 4, 1, 2); SETLDS(64, 5, 1, 2);
+            SETLDS(32, 1, 0, 1); SETLDS(32, 3, 1, 1); SETLDS(32, 4, 1, 1); SETLDS(32, 5, 1, 1);
+            SETLDS(32, 1, 0, 2); SETLDS(32, 3, 1, 2); SETLDS(32, 4, 1, 2); SETLDS(32, 5, 1, 2);
 #undef SETLDS
-#define SETLDS128(CC, NO) (void)hipFuncSetAttribute((const void*)f_backward<128, CC, NO, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b)
-            SETLDS128(1, 1); SETLDS128(3, 1); SETLDS128(5, 1); SETLDS128(1, 2); SETLDS128(3, 2); SETLDS128(5, 2);
+#define SETLDS128(CC, EE, NO) (void)hipFuncSetAttribute((const void*)f_backward<128, CC, EE, NO, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b)
+            SETLDS128(1, 0, 1); SETLDS128(3, 1, 1); SETLDS128(4, 1, 1); SETLDS128(1, 0, 2); SETLDS128(3, 1, 2); SETLDS128(4, 1, 2);
 #undef SETLDS128
+#endif
         }
     }
     if (ok) {
@@ -766,7 +805,7 @@ int gpe_bind_points(gpe_engine* e, const float* d_x, int64_t n_local, const floa
     if (!e) return GPE_ERR_INVALID;
     if (!d_x || n_local <= 0) FAIL(e, GPE_ERR_INVALID, "bind_points: need n_local > 0 points");
     if (e->cfg.potential == GPE_POT_PRECOMPUTED && !d_V) FAIL(e, GPE_ERR_INVALID, "precomputed potential requested but d_V is NULL");
-    int rc = setup_batch(e, e->main, d_x, n_local, 1 + 2 * e->nd.dim, true, d_V);
+    int rc = setup_batch(e, e->main, d_x, n_local, e->nd.dim + 2, 1, true, d_V);     // value, dim first derivatives, Laplacian
     if (rc) return rc;
     if (e->cfg.w_sym != 0.f) {
         // symmetry batch: [x ; -x], value only
@@ -775,7 +814,7 @@ int gpe_bind_points(gpe_engine* e, const float* d_x, int64_t n_local, const floa
             float* xs = nullptr;
             Batch tmp;
             if ((rc = dev_alloc(e, &tmp, &xs, (size_t)2 * n_local * e->nd.dim))) return rc;
-            if ((rc = setup_batch(e, e->sym, xs, 2 * n_local, 1, false, nullptr))) return rc;
+            if ((rc = setup_batch(e, e->sym, xs, 2 * n_local, 1, 0, false, nullptr))) return rc;
             e->sym.allocs.push_back(tmp.allocs[0]);
             e->sym.xown = xs;
         }
@@ -792,7 +831,7 @@ int gpe_bind_boundary(gpe_engine* e, const float* d_xb, int64_t n_b, const float
     if (!e) return GPE_ERR_INVALID;
     if (!d_xb || n_b <= 0) { free_batch(e->bc); e->bc_target = nullptr; return GPE_OK; }
     e->bc_target = d_target;
-    int rc = setup_batch(e, e->bc, d_xb, n_b, 1, false, nullptr);
+    int rc = setup_batch(e, e->bc, d_xb, n_b, 1, 0, false, nullptr);
     if (rc) return rc;
     HIPCHK(e, hipStreamSynchronize(e->stream));
     return GPE_OK;
@@ -816,15 +855,15 @@ int gpe_bind_base(gpe_engine* e, const float* d_phi, const float* d_phi1, const 
 }
 
 // ---- forward-only ----------------------------------------------------------------------------------
-static int aux_forward(gpe_engine* e, const float* d_x, int64_t n, int C) {
-    int rc = setup_batch(e, e->aux, d_x, n, C, true, nullptr, /*with_store=*/false);
+static int aux_forward(gpe_engine* e, const float* d_x, int64_t n, int C, int E) {
+    int rc = setup_batch(e, e->aux, d_x, n, C, E, true, nullptr, /*with_store=*/false);
     if (rc) return rc;
     return mlp_forward(e, e->aux, false);
 }
 
 int gpe_forward(gpe_engine* e, const float* d_x, int64_t n, float* d_out) {
     if (!e || !d_x || !d_out || n <= 0) return GPE_ERR_INVALID;
-    int rc = aux_forward(e, d_x, n, 1);
+    int rc = aux_forward(e, d_x, n, 1, 0);
     if (rc) return rc;
     hipLaunchKernelGGL(k_copy_values, dim3(cdiv(n, 256)), dim3(256), 0, e->stream, e->ph, d_x, e->aux.O, d_out, n, e->aux.ld, e->nd.n_out);
     HIPCHK(e, hipGetLastError());
@@ -835,7 +874,7 @@ int gpe_forward(gpe_engine* e, const float* d_x, int64_t n, float* d_out) {
 int gpe_forward_jets(gpe_engine* e, const float* d_x, int64_t n, float* d_jets) {
     if (!e || !d_x || !d_jets || n <= 0) return GPE_ERR_INVALID;
     const int C = 1 + 2 * e->nd.dim;
-    int rc = aux_forward(e, d_x, n, C);
+    int rc = aux_forward(e, d_x, n, C, e->nd.dim);        // full diagonal second derivatives: E = dim
     if (rc) return rc;
     hipLaunchKernelGGL(k_copy_jets, dim3(cdiv(n, 256)), dim3(256), 0, e->stream, e->aux.O, d_jets, n, e->aux.ld, e->nd.n_out, C);
     HIPCHK(e, hipGetLastError());
@@ -847,7 +886,7 @@ int gpe_eval_density(gpe_engine* e, const float* d_x, int64_t n, float dx, int a
     if (!e || !d_x || n <= 0) return GPE_ERR_INVALID;
     if (e->cfg.base_mode >= 0 && e->cfg.base_kind == GPE_BASE_PRECOMPUTED)
         FAIL(e, GPE_ERR_INVALID, "eval_density needs an analytic base (the precomputed base exists on the bound points only)");
-    int rc = aux_forward(e, d_x, n, 1);
+    int rc = aux_forward(e, d_x, n, 1, 0);
     if (rc) return rc;
     double* acc = e->dsc() + 1;
     HIPCHK(e, hipMemsetAsync(acc, 0, sizeof(double), e->stream));
@@ -866,7 +905,7 @@ static unsigned head_grid(gpe_engine* e, int64_t n) { return (unsigned)std::min<
 static int launch_head_pde(gpe_engine* e) {
     Batch& b = e->main;
     dim3 g(head_grid(e, b.n));
-    DISPATCH_C(b.C, hipLaunchKernelGGL((k_head_pde<CC>), g, dim3(256), 0, e->stream, e->ph, e->base_norm, b.x, b.V, b.O,
+    DISPATCH_TRAIN(b, hipLaunchKernelGGL((k_head_pde<CC, EE>), g, dim3(256), 0, e->stream, e->ph, e->base_norm, b.x, b.V, b.O,
                                         (const float* const*)e->orth_dev, b.u, b.Hu, b.ux, e->sums(), b.n, b.ld));
     HIPCHK(e, hipGetLastError());
     return GPE_OK;
@@ -874,7 +913,7 @@ static int launch_head_pde(gpe_engine* e) {
 static int launch_seed_pde(gpe_engine* e, float* d_resid, int want_seeds) {
     Batch& b = e->main;
     dim3 g(head_grid(e, b.n));
-    DISPATCH_C(b.C, hipLaunchKernelGGL((k_seed_pde<CC>), g, dim3(256), 0, e->stream, e->ph, b.x, b.V,
+    DISPATCH_TRAIN(b, hipLaunchKernelGGL((k_seed_pde<CC, EE>), g, dim3(256), 0, e->stream, e->ph, b.x, b.V,
                                         (const float* const*)e->orth_dev, b.u, b.Hu, b.ux, e->sums(), b.Ob, d_resid, e->dsc(),
                                         b.n, b.ld, want_seeds));
     HIPCHK(e, hipGetLastError());
@@ -985,7 +1024,7 @@ int gpe_bind_target(gpe_engine* e, const float* d_target) {
     if (e->main.n <= 0) FAIL(e, GPE_ERR_STATE, "bind_target before bind_points");
     e->mse_target = d_target;
     if (!d_target) { free_batch(e->mse); return GPE_OK; }
-    return setup_batch(e, e->mse, e->main.x, e->main.n, 1, false, nullptr);
+    return setup_batch(e, e->mse, e->main.x, e->main.n, 1, 0, false, nullptr);
 }
 
 int gpe_mse_begin(gpe_engine* e) {
@@ -1239,11 +1278,12 @@ int gpe_debug_read_stamps(gpe_engine* e, unsigned long long out[16]) {
 
 int gpe_step_cost(const gpe_engine* e, double* flops_per_point, double* hbm_bytes_per_point) {
     if (!e) return GPE_ERR_INVALID;
-    // F_fwd = 2 d H + (1+2d) [2 H^2 (L-1) + 2 H out] (+ activations), F_step = 3 F_fwd ; B_mat = 2 (1+2d) H L 4
+    // SURVEY 8(d) with the channel count of the training batches, C = d + 2 (value, d first derivatives, Laplacian) instead of
+    // 1 + 2d:  F_fwd = 2 d H + C [2 H^2 (L-1) + 2 H out] (+ activations), F_step = 3 F_fwd ; B_mat = 2 C H L 4
     const int d = e->nd.dim, L = e->nd.n_lin - 1, H = e->nd.width[1], no = e->nd.n_out;
-    const double C = 1 + 2 * d;
+    const double C = d + 2;
     double gemm = 2.0 * d * H + C * (2.0 * H * H * (L - 1) + 2.0 * H * no);
-    double act = (double)H * L * (3 + 5 * d);
+    double act = (double)H * L * (6 + 4 * d);
     if (flops_per_point) *flops_per_point = 3.0 * (gemm + act);
     if (hbm_bytes_per_point) *hbm_bytes_per_point = 2.0 * C * H * L * 4.0;
     return GPE_OK;

@@ -167,9 +167,9 @@ GPE_DEV void stage_layer0(float* w0s, const float* __restrict__ theta, const Net
 }
 
 // stored-equivalent (t, z_k, z_kk) of hidden layer 0 for features 16nt+4q+r, recomputed from the point coordinates
-template <int H, int C>
+template <int H, int C, int E>
 GPE_DEV void layer0_st(const float* w0s, const float (&xv)[3], int nt, int q, f32x4 (&st)[C]) {
-    constexpr int D = (C - 1) / 2;
+    constexpr int D = C - 1 - E;
     const int o = 16 * nt + 4 * q;
     const f32x4 w0 = *reinterpret_cast<const f32x4*>(&w0s[o]);
     const f32x4 w1 = *reinterpret_cast<const f32x4*>(&w0s[H + o]);
@@ -179,21 +179,23 @@ GPE_DEV void layer0_st(const float* w0s, const float (&xv)[3], int nt, int q, f3
     for (int r = 0; r < 4; ++r) {
         float z = fmaf(w2[r], xv[2], fmaf(w1[r], xv[1], fmaf(w0[r], xv[0], bb[r])));
         st[0][r] = gpe_tanh(z);
-        if constexpr (D >= 1) { st[1][r] = w0[r]; st[1 + D][r] = 0.f; }
-        if constexpr (D >= 2) { st[2][r] = w1[r]; st[2 + D][r] = 0.f; }
-        if constexpr (D >= 3) { st[3][r] = w2[r]; st[3 + D][r] = 0.f; }
+        if constexpr (D >= 1) st[1][r] = w0[r];
+        if constexpr (D >= 2) st[2][r] = w1[r];
+        if constexpr (D >= 3) st[3][r] = w2[r];
+#pragma unroll
+        for (int e = 0; e < E; ++e) st[1 + D + e][r] = 0.f;      // a linear map has no second derivatives
     }
 }
 
 // WLDS: the packed hidden-hidden weights ((L-1)*H*H floats) are staged once per workgroup into LDS and the MFMA A
 // operands are read from there (ds_read_b128, ~100 cycles) instead of from L2 (~600 cycles) right before each use.
-template <int H, int C, int NOUT, bool WLDS>
+template <int H, int C, int E, int NOUT, bool WLDS>
 __global__ __launch_bounds__(256, ((C <= 5 && H <= 64) ? GPE_FWD_WAVES : 1)) void f_forward(NetDesc nd, const float* __restrict__ theta,
                                                                  const float* __restrict__ Wpk,
                                                                  const float* __restrict__ x, float* __restrict__ stored,
                                                                  float* __restrict__ O, int64_t N, int64_t ld,
                                                                  int store_acts) {
-    constexpr int D = (C - 1) / 2, NT = H / 16, NF = NT * 4;
+    constexpr int D = C - 1 - E, NT = H / 16, NF = NT * 4;
     const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4;
     const int L = nd.n_lin - 1;
     const int dim = nd.dim;
@@ -234,13 +236,15 @@ __global__ __launch_bounds__(256, ((C <= 5 && H <= 64) ? GPE_FWD_WAVES : 1)) voi
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             f32x4 st[C];
-            layer0_st<H, C>(w0s, xv, nt, q, st);
+            layer0_st<H, C, E>(w0s, xv, nt, q, st);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float zk[D > 0 ? D : 1], zkk[D > 0 ? D : 1], a[C];
+                float zk[D > 0 ? D : 1], zkk[E > 0 ? E : 1], a[C];
 #pragma unroll
-                for (int jd = 0; jd < D; ++jd) { zk[jd] = st[1 + jd][r]; zkk[jd] = 0.f; }
-                act_from_stored<D>(st[0][r], zk, zkk, shift, a);
+                for (int jd = 0; jd < D; ++jd) zk[jd] = st[1 + jd][r];
+#pragma unroll
+                for (int e = 0; e < E; ++e) zkk[e] = 0.f;
+                act_from_stored<D, E>(st[0][r], zk, zkk, shift, a);
 #pragma unroll
                 for (int c = 0; c < C; ++c) bufA[c][nt * 4 + r] = a[c];
             }
@@ -270,15 +274,14 @@ __global__ __launch_bounds__(256, ((C <= 5 && H <= 64) ? GPE_FWD_WAVES : 1)) voi
                 for (int r = 0; r < 4; ++r) {
                     float t = gpe_tanh(acc[0][r]);
                     tt[r] = t;
-                    float s = fmaf(-t, t, 1.0f);
-                    float ts2 = 2.0f * t * s;
-                    a_out[0][nt * 4 + r] = t + shift;
+                    float zk[D > 0 ? D : 1], zkk[E > 0 ? E : 1], a[C];
 #pragma unroll
-                    for (int jd = 0; jd < D; ++jd) {
-                        float zk = acc[1 + jd][r], zkk = acc[1 + D + jd][r];
-                        a_out[1 + jd][nt * 4 + r] = s * zk;
-                        a_out[1 + D + jd][nt * 4 + r] = fmaf(s, zkk, -ts2 * zk * zk);
-                    }
+                    for (int jd = 0; jd < D; ++jd) zk[jd] = acc[1 + jd][r];
+#pragma unroll
+                    for (int e = 0; e < E; ++e) zkk[e] = acc[1 + D + e][r];
+                    act_from_stored<D, E>(t, zk, zkk, shift, a);
+#pragma unroll
+                    for (int c = 0; c < C; ++c) a_out[c][nt * 4 + r] = a[c];
                 }
                 if (store_acts) {
                     float* sp = stored + ((((size_t)tile * (L - 1) + (j - 1)) * C) * NT + nt) * 256 + lane * 4;
@@ -348,14 +351,14 @@ GPE_DEV unsigned long long stamp_now() {
 // H > 64 ("GACC"): the parameter vector no longer fits LDS (266 KB for [2,128x5,1]); gradients are accumulated with
 // global float atomics into one of `nslab` L2-resident slabs (blockIdx % nslab) that the host zeroes before the launch --
 // 16 KB of atomic traffic per point for cfg3, well inside the chip's ~1.3 TB/s atomic rate at the kernel's compute rate.
-template <int H, int C, int NOUT, bool WLDS, int NHH>
+template <int H, int C, int E, int NOUT, bool WLDS, int NHH>
 __global__ __launch_bounds__((NHH > 0 ? 256 : (WLDS ? 512 : 256)), ((NHH > 0 || H > 64) ? 1 : (C <= 5 ? GPE_BWD_WAVES : 1))) void f_backward(NetDesc nd, const float* __restrict__ theta,
                                                                   const float* __restrict__ WpkT,
                                                                   const float* __restrict__ x,
                                                                   const float* __restrict__ stored,
                                                                   const float* __restrict__ Ob, float* __restrict__ gslab,
                                                                   int64_t N, int64_t ld, int Ppad, int nslab) {
-    constexpr int D = (C - 1) / 2, NT = H / 16, NF = NT * 4;
+    constexpr int D = C - 1 - E, NT = H / 16, NF = NT * 4;
     constexpr int NTHR = (NHH > 0) ? 256 : (WLDS ? 512 : 256);
     constexpr bool RACC = NHH > 0;
     constexpr bool GACC = H > 64;
@@ -420,7 +423,7 @@ __global__ __launch_bounds__((NHH > 0 ? 256 : (WLDS ? 512 : 256)), ((NHH > 0 || 
 #pragma unroll
                 for (int c = 0; c < C; ++c) st[c] = *reinterpret_cast<const f32x4*>(sp + (size_t)c * NT * 256);
             } else {
-                layer0_st<H, C>(w0s, xv, kt, q, st);
+                layer0_st<H, C, E>(w0s, xv, kt, q, st);
             }
         };
 
@@ -441,10 +444,12 @@ __global__ __launch_bounds__((NHH > 0 ? 256 : (WLDS ? 512 : 256)), ((NHH > 0 || 
                 for (int o = 0; o < NOUT; ++o) wo[o] = *reinterpret_cast<const f32x4*>(&Wo[o * H + 16 * nt + 4 * q]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float zk[D > 0 ? D : 1], zkk[D > 0 ? D : 1], a[C], ab[C], zv[C];
+                    float zk[D > 0 ? D : 1], zkk[E > 0 ? E : 1], a[C], ab[C], zv[C];
 #pragma unroll
-                    for (int jd = 0; jd < D; ++jd) { zk[jd] = st[1 + jd][r]; zkk[jd] = st[1 + D + jd][r]; }
-                    act_from_stored<D>(st[0][r], zk, zkk, shift, a);
+                    for (int jd = 0; jd < D; ++jd) zk[jd] = st[1 + jd][r];
+#pragma unroll
+                    for (int e = 0; e < E; ++e) zkk[e] = st[1 + D + e][r];
+                    act_from_stored<D, E>(st[0][r], zk, zkk, shift, a);
 #pragma unroll
                     for (int o = 0; o < NOUT; ++o) {
                         float g = 0.f;
@@ -459,7 +464,7 @@ __global__ __launch_bounds__((NHH > 0 ? 256 : (WLDS ? 512 : 256)), ((NHH > 0 || 
                         for (int o = 0; o < NOUT; ++o) v = fmaf(wo[o][r], ob[o][c], v);
                         ab[c] = v;
                     }
-                    act_adjoint<D>(st[0][r], zk, zkk, ab, zv);
+                    act_adjoint<D, E>(st[0][r], zk, zkk, ab, zv);
 #pragma unroll
                     for (int c = 0; c < C; ++c) zb[c][nt * 4 + r] = zv[c];
                 }
@@ -543,13 +548,15 @@ __global__ __launch_bounds__((NHH > 0 ? 256 : (WLDS ? 512 : 256)), ((NHH > 0 || 
                     if (kt + 1 < NT) load_st(j - 1, kt + 1, stn);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float zk[D > 0 ? D : 1], zkk[D > 0 ? D : 1], a[C], ab[C], zv[C];
+                        float zk[D > 0 ? D : 1], zkk[E > 0 ? E : 1], a[C], ab[C], zv[C];
 #pragma unroll
-                        for (int jd = 0; jd < D; ++jd) { zk[jd] = st[1 + jd][r]; zkk[jd] = st[1 + D + jd][r]; }
-                        act_from_stored<D>(st[0][r], zk, zkk, shift, a);
+                        for (int jd = 0; jd < D; ++jd) zk[jd] = st[1 + jd][r];
+#pragma unroll
+                    for (int e = 0; e < E; ++e) zkk[e] = st[1 + D + e][r];
+                        act_from_stored<D, E>(st[0][r], zk, zkk, shift, a);
 #pragma unroll
                         for (int c = 0; c < C; ++c) { xa[c][r] = a[c]; ab[c] = zb[c][kt * 4 + r]; }
-                        act_adjoint<D>(st[0][r], zk, zkk, ab, zv);
+                        act_adjoint<D, E>(st[0][r], zk, zkk, ab, zv);
 #pragma unroll
                         for (int c = 0; c < C; ++c) zb[c][kt * 4 + r] = zv[c];
                     }

@@ -4,7 +4,7 @@
 // fallback for shapes the fused MFMA set (gpe_fused.h) does not take.
 //
 // Stored per hidden layer h (for the reverse pass):  S_h[0] = t = tanh(z),  S_h[1+j] = dz/dx_j,
-// S_h[1+D+j] = d2z/dx_j^2.  Activation jets are recomputed from S on load (gpe_common.h:act_from_stored).
+// S_h[1+D+e] = second-order channel e (d2z/dx_e^2, or the Laplacian when E = 1 < D; gpe_common.h).  Activation jets are recomputed from S on load (gpe_common.h:act_from_stored).
 // Replaces: nn.Sequential forward + the two torch.autograd.grad(create_graph=True) calls + loss.backward() of
 // refine/harmonic_pinn_simulation.py:121-125,158-172,358 (2D: src/gross_pitaevskii_2D.py:183-188).
 #pragma once
@@ -14,11 +14,11 @@
 
 // lin: index of the linear map.  Sprev: stored of hidden layer lin-1 (NULL for lin==0).  Out: stored of hidden
 // layer lin, or the output jets O when lin == n_lin-1.
-template <int C>
+template <int C, int E>
 __global__ __launch_bounds__(256) void g_fwd_layer(NetDesc nd, int lin, const float* __restrict__ theta,
                                                    const float* __restrict__ x, const float* __restrict__ Sprev,
                                                    float* __restrict__ Out, int64_t N, int64_t ld) {
-    constexpr int D = (C - 1) / 2;
+    constexpr int D = C - 1 - E;
     int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (m >= N) return;
     const int K = nd.width[lin], Ho = nd.width[lin + 1];
@@ -50,13 +50,12 @@ __global__ __launch_bounds__(256) void g_fwd_layer(NetDesc nd, int lin, const fl
     } else {
         for (int k = 0; k < K; ++k) {
             float t = Sprev[((int64_t)0 * K + k) * ld + m];
-            float zk[D > 0 ? D : 1], zkk[D > 0 ? D : 1], a[C];
+            float zk[D > 0 ? D : 1], zkk[E > 0 ? E : 1], a[C];
 #pragma unroll
-            for (int j = 0; j < D; ++j) {
-                zk[j] = Sprev[((int64_t)(1 + j) * K + k) * ld + m];
-                zkk[j] = Sprev[((int64_t)(1 + D + j) * K + k) * ld + m];
-            }
-            act_from_stored<D>(t, zk, zkk, nd.shift, a);
+            for (int j = 0; j < D; ++j) zk[j] = Sprev[((int64_t)(1 + j) * K + k) * ld + m];
+#pragma unroll
+            for (int j = 0; j < E; ++j) zkk[j] = Sprev[((int64_t)(1 + D + j) * K + k) * ld + m];
+            act_from_stored<D, E>(t, zk, zkk, nd.shift, a);
 #pragma unroll
             for (int f = 0; f < G_FB; ++f) {
                 int n = min(n0 + f, Ho - 1);
@@ -78,23 +77,22 @@ __global__ __launch_bounds__(256) void g_fwd_layer(NetDesc nd, int lin, const fl
 }
 
 // Zb = act_adjoint(Ab, S_h) in place.  grid (ceil(N/256), H).
-template <int C>
+template <int C, int E>
 __global__ __launch_bounds__(256) void g_bwd_act(int H, const float* __restrict__ S, float* __restrict__ A,
                                                  int64_t N, int64_t ld) {
-    constexpr int D = (C - 1) / 2;
+    constexpr int D = C - 1 - E;
     int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (m >= N) return;
     int n = blockIdx.y;
     float t = S[((int64_t)0 * H + n) * ld + m];
-    float zk[D > 0 ? D : 1], zkk[D > 0 ? D : 1], ab[C], zb[C];
+    float zk[D > 0 ? D : 1], zkk[E > 0 ? E : 1], ab[C], zb[C];
 #pragma unroll
-    for (int j = 0; j < D; ++j) {
-        zk[j] = S[((int64_t)(1 + j) * H + n) * ld + m];
-        zkk[j] = S[((int64_t)(1 + D + j) * H + n) * ld + m];
-    }
+    for (int j = 0; j < D; ++j) zk[j] = S[((int64_t)(1 + j) * H + n) * ld + m];
+#pragma unroll
+    for (int j = 0; j < E; ++j) zkk[j] = S[((int64_t)(1 + D + j) * H + n) * ld + m];
 #pragma unroll
     for (int c = 0; c < C; ++c) ab[c] = A[((int64_t)c * H + n) * ld + m];
-    act_adjoint<D>(t, zk, zkk, ab, zb);
+    act_adjoint<D, E>(t, zk, zkk, ab, zb);
 #pragma unroll
     for (int c = 0; c < C; ++c) A[((int64_t)c * H + n) * ld + m] = zb[c];
 }
@@ -138,11 +136,11 @@ __global__ __launch_bounds__(256) void g_bwd_data(NetDesc nd, int lin, const flo
 // grad W[n][k] += sum_{c,m} Zb[c][n][m] * A[c][k][m],  grad b[n] += sum_m Zb[0][n][m].
 // One block per (n, 16-wide k block); the block walks all points -> deterministic, no atomics.
 #define G_KB 16
-template <int C>
+template <int C, int E>
 __global__ __launch_bounds__(256) void g_bwd_weight(NetDesc nd, int lin, const float* __restrict__ x,
                                                     const float* __restrict__ Sprev, const float* __restrict__ Zb,
                                                     float* __restrict__ grad, int64_t N, int64_t ld) {
-    constexpr int D = (C - 1) / 2;
+    constexpr int D = C - 1 - E;
     __shared__ double red[4];
     const int K = nd.width[lin], Ho = nd.width[lin + 1];
     const int n = blockIdx.x, k0 = blockIdx.y * G_KB;
@@ -168,13 +166,12 @@ __global__ __launch_bounds__(256) void g_bwd_weight(NetDesc nd, int lin, const f
                 p[i] += v;
             } else {
                 float t = Sprev[((int64_t)0 * K + k) * ld + m];
-                float zk[D > 0 ? D : 1], zkk[D > 0 ? D : 1], a[C];
+                float zk[D > 0 ? D : 1], zkk[E > 0 ? E : 1], a[C];
 #pragma unroll
-                for (int j = 0; j < D; ++j) {
-                    zk[j] = Sprev[((int64_t)(1 + j) * K + k) * ld + m];
-                    zkk[j] = Sprev[((int64_t)(1 + D + j) * K + k) * ld + m];
-                }
-                act_from_stored<D>(t, zk, zkk, nd.shift, a);
+                for (int j = 0; j < D; ++j) zk[j] = Sprev[((int64_t)(1 + j) * K + k) * ld + m];
+#pragma unroll
+                for (int j = 0; j < E; ++j) zkk[j] = Sprev[((int64_t)(1 + D + j) * K + k) * ld + m];
+                act_from_stored<D, E>(t, zk, zkk, nd.shift, a);
                 float v = 0.f;
 #pragma unroll
                 for (int c = 0; c < C; ++c) v = fmaf(z[c], a[c], v);

@@ -9,12 +9,12 @@
 
 // u-jets (value, first, second derivatives) of component o at point m from NN output jets.
 // bptr: device array of pointers; [0..3] orthogonality modes, [4..6] precomputed base phi, phi', phi''.
-template <int C>
+template <int C, int E>
 GPE_DEV void load_u_jets(const Phys& ph, const float* __restrict__ O, int64_t ld, int64_t m, int o,
                          const float* xv, float base_norm, const float* const* __restrict__ bptr, float* U /*[C]*/) {
 #pragma unroll
     for (int c = 0; c < C; ++c) U[c] = ph.perturb_scale * O[((int64_t)c * ph.n_out + o) * ld + m];
-    if constexpr (C == 3) {
+    if constexpr (C == 3 && E == 1) {
         if (ph.envelope == GPE_ENV_SIN) {              // psi = o f : product rule on the jets
             float f, f1, f2;
             envelope_at(ph, xv[0], f, f1, f2);
@@ -33,13 +33,13 @@ GPE_DEV void load_u_jets(const Phys& ph, const float* __restrict__ O, int64_t ld
 }
 
 // ---- phase 1: u, Hu per point; block partial sums into sums[] (double atomics) ---------------------
-template <int C>
+template <int C, int E>
 __global__ __launch_bounds__(256) void k_head_pde(Phys ph, float base_norm, const float* __restrict__ x,
                                                   const float* __restrict__ Vpre, const float* __restrict__ O,
                                                   const float* const* __restrict__ orth, float* __restrict__ u_out,
                                                   float* __restrict__ Hu_out, float* __restrict__ ux_out,
                                                   double* __restrict__ sums, int64_t N, int64_t ld) {
-    constexpr int D = (C - 1) / 2;
+    constexpr int D = C - 1 - E;
     __shared__ double red[4];
     double num = 0.0, den = 0.0, so[GPE_MAX_ORTH] = {0.0, 0.0, 0.0, 0.0};
     double rzk = 0.0, rzp = 0.0, rzi = 0.0;
@@ -49,12 +49,12 @@ __global__ __launch_bounds__(256) void k_head_pde(Phys ph, float base_norm, cons
         for (int k = 0; k < ph.dim; ++k) xv[k] = x[m * ph.dim + k];
         float V = potential_at(ph, xv, Vpre, m);
         float U[2][C];
-        for (int o = 0; o < ph.n_out; ++o) load_u_jets<C>(ph, O, ld, m, o, xv, base_norm, orth, U[o]);
+        for (int o = 0; o < ph.n_out; ++o) load_u_jets<C, E>(ph, O, ld, m, o, xv, base_norm, orth, U[o]);
         float Hu[2] = {0.f, 0.f};
         if (!ph.complex_psi) {
             float u = U[0][0], lap = 0.f;
 #pragma unroll
-            for (int j = 0; j < D; ++j) lap += U[0][1 + D + j];
+            for (int j = 0; j < E; ++j) lap += U[0][1 + D + j];
             float inter = ph.abs_power ? ph.gamma * ipowf(fabsf(u), ph.p - 1) * u : ph.gamma * ipowf(u, ph.p);
             Hu[0] = -ph.kin * lap + V * u + inter;
         } else {
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void k_head_pde(Phys ph, float base_norm, cons
             float rho = ur * ur + ui * ui;
             float lr = 0.f, li = 0.f;
 #pragma unroll
-            for (int j = 0; j < D; ++j) { lr += U[0][1 + D + j]; li += U[1][1 + D + j]; }
+            for (int j = 0; j < E; ++j) { lr += U[0][1 + D + j]; li += U[1][1 + D + j]; }
             Hu[0] = -ph.kin * lr + V * ur + ph.gamma * rho * ur;
             Hu[1] = -ph.kin * li + V * ui + ph.gamma * rho * ui;
             if (ph.omega_rot != 0.f && D >= 2) {
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void k_head_pde(Phys ph, float base_norm, cons
             den += (double)(u * u);
         }
         for (int j = 0; j < ph.n_orth; ++j) so[j] += (double)(orth[j][m] * U[0][0]);
-        if constexpr (C == 3) {
+        if constexpr (D == 1) {
             if (ph.w_riesz != 0.f) {            // Paper nb c6:L163-174
                 const float u = U[0][0], ux = U[0][1];
                 ux_out[m] = ux;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void k_head_pde(Phys ph, float base_norm, cons
 
 // ---- phase 2: residual + seeds -------------------------------------------------------------------
 // lambda = num/den (global sums), r = Hu - lambda u, sum r^2 -> gtail[GT_SUM_R2]; Ob = dLoss/dO.
-template <int C>
+template <int C, int E>
 __global__ __launch_bounds__(256) void k_seed_pde(Phys ph, const float* __restrict__ x, const float* __restrict__ Vpre,
                                                   const float* const* __restrict__ orth,
                                                   const float* __restrict__ u_in, const float* __restrict__ Hu_in,
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void k_seed_pde(Phys ph, const float* __restri
                                                   const double* __restrict__ sums, float* __restrict__ Ob,
                                                   float* __restrict__ resid_out, double* __restrict__ sum_r2, int64_t N,
                                                   int64_t ld, int want_seeds) {
-    constexpr int D = (C - 1) / 2;
+    constexpr int D = C - 1 - E;
     __shared__ double red[4];
     double sr2 = 0.0;
     for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < N; m += (int64_t)gridDim.x * 256) {
@@ -156,14 +156,16 @@ __global__ __launch_bounds__(256) void k_seed_pde(Phys ph, const float* __restri
                 float Ub[C];
                 Ub[0] = ub[o];
 #pragma unroll
-                for (int j = 0; j < D; ++j) { Ub[1 + j] = 0.f; Ub[1 + D + j] = -ph.kin * rb[o]; }
-                if constexpr (C == 3) {
+                for (int j = 0; j < D; ++j) Ub[1 + j] = 0.f;
+#pragma unroll
+                for (int j = 0; j < E; ++j) Ub[1 + D + j] = -ph.kin * rb[o];
+                if constexpr (D == 1) {
                     if (ph.w_riesz != 0.f) {    // d(w_riesz E)/du, /du_x with E = (K + Pv + Ig)/den
                         const float den = (float)sums[S_DEN];
-                        const float E = (float)((sums[S_RZ_K] + sums[S_RZ_P] + sums[S_RZ_I]) / sums[S_DEN]);
+                        const float Erz = (float)((sums[S_RZ_K] + sums[S_RZ_P] + sums[S_RZ_I]) / sums[S_DEN]);
                         const float uu = u[0];
                         const float sg = uu < 0.f ? -1.f : 1.f;
-                        Ub[0] += ph.w_riesz * ((2.f * V * uu + ph.gamma * sg * ipowf(fabsf(uu), ph.p)) - 2.f * E * uu) / den;
+                        Ub[0] += ph.w_riesz * ((2.f * V * uu + ph.gamma * sg * ipowf(fabsf(uu), ph.p)) - 2.f * Erz * uu) / den;
                         Ub[1] += ph.w_riesz * ux_in[m] / den;
                     }
                 }
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(256) void k_seed_pde(Phys ph, const float* __restri
                     if (o == 1) { Ub[2] += -Om * xv[0] * rb[0]; Ub[1] += Om * xv[1] * rb[0]; }
                     else        { Ub[2] += Om * xv[0] * rb[1];  Ub[1] += -Om * xv[1] * rb[1]; }
                 }
-                if constexpr (C == 3) {
+                if constexpr (D == 1) {
                     if (ph.envelope == GPE_ENV_SIN) {      // adjoint of psi = o f
                         float f, f1, f2;
                         envelope_at(ph, xv[0], f, f1, f2);
