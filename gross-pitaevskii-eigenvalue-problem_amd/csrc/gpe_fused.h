@@ -560,6 +560,7 @@ __global__ __launch_bounds__((NHH > 0 ? 256 : (WLDS ? 512 : 256)), ((NHH > 0 || 
 #pragma unroll
                         for (int c = 0; c < C; ++c) zb[c][kt * 4 + r] = zv[c];
                     }
+                    STAMP(7);
                     tiles_transpose<C>(xa, xt, TT, m, q);
                     STAMP(3);
                     if constexpr (RACC) {

@@ -3,7 +3,7 @@
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["GPE_HIP_LIB"] = os.path.join(ROOT, "build/variants/libgpe_stamp.so")
+os.environ.setdefault("GPE_HIP_LIB", os.path.join(ROOT, "build/variants/libgpe_stamp.so"))
 import numpy as np, torch
 import bench, gpe_pinn
 wl = bench.WORKLOADS["ns_2d_4x64"]
@@ -19,7 +19,7 @@ eng.run(3)
 eng.lib.gpe_debug_read_stamps(eng._h, out)
 v = np.array(list(out)[:8], dtype=np.float64)
 names = ["0 seeds+output layer", "1 bias grads", "2 Zb transposes", "3 X load+recompute+transpose", "4 B2 MFMA+LDS add",
-         "5 B1 MFMA+adjoint+copy", "6 layer-0 grads", "7 -"]
+         "5 B1 MFMA+adjoint+copy", "6 layer-0 grads", "7 X load+recompute+adjoint (3 = its transposes)"]
 tot = v.sum()
 for n, c in zip(names, v):
     print("%-32s %6.2f %%   %.3e wave-cycles" % (n, 100 * c / tot, c))
