@@ -183,16 +183,16 @@ def main():
         ach = 2.0 * f_fwd * n_local / bwd_s / 1e12 if bwd_s > 0 else 0.0
         ach_f = f_fwd * n_local / fwd_s / 1e12 if fwd_s > 0 else 0.0
         # HBM bytes per launch of the dominant kernel from the committed PMC run of this same workload
-        # (profiles/r01/traffic_ns_v3.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 1/2-fetch correction applied)
+        # (profiles/r01/traffic_ns_v5.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 1/2-fetch correction applied)
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01", "traffic_ns_v3.json")
+        tpath = os.path.join(ROOT, "profiles", "r01", "traffic_ns_v5.json")
         if args.workload == "ns_2d_4x64" and os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 for k, v in tj["kernels"].items():
                     if "f_backward" in k:
                         traffic = v["hbm_bytes_per_point"] * n_local
-                        traffic_src = "profiles/r01/traffic_ns_v3.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                        traffic_src = "profiles/r01/traffic_ns_v5.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
             except Exception:
                 pass
         out = {
