@@ -463,3 +463,59 @@ def test_golden_paper_riesz_oplevel(name, path):
     assert abs(sc2["loss"] - 2 * osc["loss"]) < 2e-4 * 2 * osc["loss"]
     assert H.rel_err(eng.get_grad(), 2 * ograd) < 5e-5
     eng.close()
+
+
+# ---- execution-mode switches of the engine give the same numbers --------------------------------------------------------------
+def _trajectory(env, kw, N, steps, use_run):
+    """(losses, final parameters) of `steps` steps on a fresh engine created under the environment `env`."""
+    import os
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        x, flat, x_bc = _inputs(kw, N)
+        eng = make_engine(go.Problem(**kw), flat, x, x_bc)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    if use_run:
+        eng.run(steps)
+        losses = [h["loss"] for h in eng.read_history(1, steps)]
+    else:
+        losses = [eng.step()["loss"] for _ in range(steps)]
+    theta = eng.get_params()
+    grad = eng.get_grad()
+    eng.close()
+    return np.array(losses), theta, grad
+
+
+@pytest.mark.parametrize("kw,N", [(dict(layers=[1, 64, 64, 64, 1], activation=1, gamma=5.0, base_mode=0, perturb_scale=0.05,
+                                        dx=12 / 499), 500),
+                                  (dict(layers=[2, 64, 64, 64, 64, 1], gamma=50.0, dx=0.01), 777)])
+def test_side_stream_and_graph_replay_change_nothing(kw, N):
+    """Boundary batch on the side stream (default) vs in line (GPE_SIDE_STREAM=0) vs hipGraph replay of gpe_run (GPE_GRAPH=1):
+    same kernels and arithmetic; the fused kernels accumulate weight gradients with LDS float atomics from several waves, so
+    two runs agree to fp32 round-off, not bit for bit (the trajectories stay within 1e-5 over 12 steps)."""
+    def same(a, b):
+        return np.abs(np.asarray(a) - np.asarray(b)).max() <= 1e-5 * max(1.0, np.abs(np.asarray(b)).max())
+    base_l, base_t, _ = _trajectory({"GPE_SIDE_STREAM": "0", "GPE_GRAPH": "0"}, kw, N, 12, use_run=True)
+    for env in ({"GPE_SIDE_STREAM": "1", "GPE_GRAPH": "0"}, {"GPE_SIDE_STREAM": "1", "GPE_GRAPH": "1"},
+                {"GPE_SIDE_STREAM": "0", "GPE_GRAPH": "1"}):
+        l, t, _ = _trajectory(env, kw, N, 12, use_run=True)
+        assert same(l, base_l), env
+        assert same(t, base_t), env
+    l, t, _ = _trajectory({}, kw, N, 12, use_run=False)         # step-by-step with host synchronisation
+    assert same(l, base_l) and same(t, base_t)
+
+
+def test_staged_and_unstaged_kernel_variants_agree():
+    """Batches below / above the staging threshold use different fused kernels (weights from L2 + LDS-atomic gradients vs
+    LDS-staged weights + register-resident gradients); one step from the same state must agree to fp32 round-off."""
+    kw = dict(layers=[2, 64, 64, 64, 64, 1], gamma=50.0, dx=0.01)
+    N = 4096
+    la, _, ga = _trajectory({"GPE_STAGE_MIN_TILES": "0"}, kw, N, 1, use_run=False)          # always staged
+    lb, _, gb = _trajectory({"GPE_STAGE_MIN_TILES": "1000000000"}, kw, N, 1, use_run=False)  # never staged
+    assert abs(la[0] - lb[0]) <= 1e-6 * abs(la[0])
+    assert H.rel_err(ga, gb) < 2e-6
