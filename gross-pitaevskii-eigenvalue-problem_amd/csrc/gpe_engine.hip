@@ -202,6 +202,8 @@ struct gpe_engine {
     bool fwd_wlds = false, bwd_wlds = false;      // hidden-hidden weights staged in LDS by the fused kernels
     bool bwd_racc = false;                        // reverse kernel keeps the H x H weight gradients in registers (1 wave/SIMD)
     int nslab_g = 16;                             // H = 128: number of global-atomic gradient slabs
+    int coop = 1;                                 // cooperative reverse kernel: 0 never, 1 whenever compiled for the shape, -1 by batch size
+    int64_t coop_max_tiles = 0;
     int64_t stage_min_tiles = 0;                  // batches with fewer 16-point tiles use the unstaged kernels (latency-bound regime)
     hipStream_t side = nullptr;                   // boundary batch runs here, concurrently with the collocation batch
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -343,11 +345,41 @@ static void launch_f_forward(gpe_engine* e, Batch& b, unsigned grid, int store) 
     else
         F_LAUNCH(f_forward, HH, CC, EE, false, grid, 256, fused_fwd_lds(e, false), e->nd, e->theta, e->Wpk, b.x, b.stored, b.O, b.n, b.ld, store);
 }
-// reverse-kernel variant for one batch: 2 = weight gradients in registers (1 wave/SIMD), 1 = 512-thread LDS-weight variant,
+// reverse-kernel variant for one batch: 3 = cooperative (a workgroup per tile, a wave per 16-feature slice),
+// 2 = weight gradients in registers (1 wave/SIMD), 1 = 512-thread LDS-weight variant,
 // 0 = plain (LDS-atomic gradients, weights from L2; also the fastest when every wave sees only a tile or two)
+static bool coop_shape(gpe_engine* e) { return e->H <= 64 && e->nd.n_lin - 2 >= 1 && e->nd.n_lin - 2 <= 3; }
 static int bwd_kind(gpe_engine* e, const Batch& b) {
+    if (coop_shape(e) && e->coop != 0 && (e->coop == 1 || (b.n + 15) / 16 <= e->coop_max_tiles)) return 3;
     if (e->H > 64 || !staged_batch(e, b)) return 0;
     return e->bwd_racc ? 2 : (e->bwd_wlds ? 1 : 0);
+}
+static size_t coop_lds(gpe_engine* e, int C) {
+    const int H = e->H, NT = H / 16, L = e->nd.n_lin - 1;
+    const size_t n_gsm = ((size_t)(L - 1 + e->nd.n_out) * H + 4 + 3) & ~(size_t)3;
+    return (n_gsm + 4 * (size_t)H) * sizeof(float) + fused_small_bytes(e) +
+           ((size_t)C * NT * 256 + 2 * (size_t)C * NT * F_TILE) * sizeof(float);
+}
+template <int HH, int CC, int EE, int NO>
+static void launch_coop_no(gpe_engine* e, Batch& b, unsigned grid, size_t lds) {
+#define CARGS e->nd, e->theta, e->WpkT, b.x, b.stored, b.Ob, e->gslab, b.n, b.ld, e->Ppad
+    switch (e->nd.n_lin - 2) {
+        case 1: hipLaunchKernelGGL((f_backward_coop<HH, CC, EE, NO, 1>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
+        case 2: hipLaunchKernelGGL((f_backward_coop<HH, CC, EE, NO, 2>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
+        default: hipLaunchKernelGGL((f_backward_coop<HH, CC, EE, NO, 3>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
+    }
+#undef CARGS
+}
+template <int HH, int CC, int EE>
+static void launch_f_backward_coop(gpe_engine* e, Batch& b, unsigned grid, size_t lds) {
+    if constexpr (HH <= 64) {
+#ifdef GPE_FAST_BUILD
+        launch_coop_no<HH, CC, EE, 1>(e, b, grid, lds);
+#else
+        if (e->nd.n_out == 1) launch_coop_no<HH, CC, EE, 1>(e, b, grid, lds);
+        else launch_coop_no<HH, CC, EE, 2>(e, b, grid, lds);
+#endif
+    }
 }
 template <int HH, int CC, int EE>
 static void launch_f_backward(gpe_engine* e, Batch& b, unsigned grid, size_t lds) {
@@ -357,7 +389,8 @@ static void launch_f_backward(gpe_engine* e, Batch& b, unsigned grid, size_t lds
     } else {
 #define BARGS e->nd, e->theta, e->WpkT, b.x, b.stored, b.Ob, e->gslab, b.n, b.ld, e->Ppad, e->nslab_g
     const int kind = bwd_kind(e, b);
-    if (kind == 2) {
+    if (kind == 3) launch_f_backward_coop<HH, CC, EE>(e, b, grid, lds);
+    else if (kind == 2) {
         switch (e->nd.n_lin - 2) {
             case 1: B_LAUNCH(HH, CC, EE, true, 1, grid, 256, lds, BARGS); break;
             case 2: B_LAUNCH(HH, CC, EE, true, 2, grid, 256, lds, BARGS); break;
@@ -473,8 +506,9 @@ static int mlp_backward(gpe_engine* e, Batch& b) {
     if (b.n <= 0) return GPE_OK;
     if (e->path == GPE_PATH_FUSED) {
         const int kind = bwd_kind(e, b);
-        unsigned grid = kind == 2 ? fused_grid(e, b.n, 4, 1) : (kind == 1 ? fused_grid(e, b.n, 8, 1) : fused_grid(e, b.n, 4, 2));
-        size_t lds = fused_bwd_lds(e, b.C, kind);
+        unsigned grid = kind == 3 ? fused_grid(e, b.n, 1, 2)
+                                  : (kind == 2 ? fused_grid(e, b.n, 4, 1) : (kind == 1 ? fused_grid(e, b.n, 8, 1) : fused_grid(e, b.n, 4, 2)));
+        size_t lds = kind == 3 ? coop_lds(e, b.C) : fused_bwd_lds(e, b.C, kind);
         const bool mark = e->prof && (&b == &e->main);
         if (mark) prof_mark(e, 1, true);
         int nred = (int)grid;
@@ -674,6 +708,10 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
                           ((size_t)e->Ppad + 4 * (size_t)H + 8 * (size_t)Cmain * F_TILE) * sizeof(float) + smallb + wb <= 160 * 1024;
             const char* envs = getenv("GPE_STAGE_MIN_TILES");
             e->stage_min_tiles = envs ? atoll(envs) : (int64_t)e->num_cu * 8;   // measured crossover: 2 tiles per wave at 1 wave/SIMD
+            const char* envc = getenv("GPE_COOP");
+            e->coop = envc ? atoi(envc) : 1;          // measured: faster than the per-wave-tile kernels at every batch size
+            const char* envm = getenv("GPE_COOP_MAX_TILES");
+            e->coop_max_tiles = envm ? atoll(envm) : 0;
             const char* envr = getenv("GPE_RACC");
             e->bwd_racc = (!envr || atoi(envr) != 0) && H <= 64 && (Lh - 1) >= 1 && (Lh - 1) <= 3 &&
                           ((size_t)e->Ppad + 4 * (size_t)H + 4 * (size_t)Cmain * F_TILE) * sizeof(float) + smallb + wb <= 160 * 1024;
@@ -685,6 +723,9 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
     (void)hipFuncSetAttribute((const void*)f_backward<HH, CC, EE, NO, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);  \
     (void)hipFuncSetAttribute((const void*)f_backward<HH, CC, EE, NO, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);  \
     (void)hipFuncSetAttribute((const void*)f_backward<HH, CC, EE, NO, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);  \
+    (void)hipFuncSetAttribute((const void*)f_backward_coop<HH, CC, EE, NO, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
+    (void)hipFuncSetAttribute((const void*)f_backward_coop<HH, CC, EE, NO, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
+    (void)hipFuncSetAttribute((const void*)f_backward_coop<HH, CC, EE, NO, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
     (void)hipFuncSetAttribute((const void*)f_forward<HH, CC, EE, NO, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_f)
 #ifdef GPE_FAST_BUILD
             SETLDS(64, 1, 0, 1); SETLDS(64, 4, 1, 1);

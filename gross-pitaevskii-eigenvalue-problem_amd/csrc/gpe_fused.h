@@ -658,6 +658,242 @@ __global__ __launch_bounds__((NHH > 0 ? 256 : (WLDS ? 512 : 256)), ((NHH > 0 || 
     }
 }
 
+// ---- cooperative reverse kernel ------------------------------------------------------------------------------------------
+// One workgroup of NT = H/16 waves works on ONE 16-point tile at a time; wave w owns the features 16w..16w+15 of every hidden
+// layer ("feature slice").  Compared with f_backward (one wave = one tile, all features):
+//   * a wave keeps only its ROWS of every H x H weight gradient: NHH*NT accumulator tiles (48 registers for NS) instead of
+//     NHH*NT*NT (192), and its K-slices of W^T stay in registers for the whole kernel (no LDS weight staging) -- so two
+//     workgroups fit a CU (2 waves per SIMD), and the VALU / LDS phases of one hide behind the MFMA phases of the other
+//     (a lone wave issues a VALU instruction only every ~8 cycles, tools/ubench/mfma_valu.hip);
+//   * a tile's latency drops ~NT-fold, which is what small batches (the reference's 4 000 points = 250 tiles) are bound by.
+// Per hidden->hidden map the waves exchange two things through LDS, with one barrier each: the adjoint jets z (point-on-lane
+// fragments, B operand of W^T z for every wave) and the transposed activation jets X^T (B operand of dW += Z X^T).
+// Elementwise work (recompute, activation adjoint), bias / output / layer-0 gradients are local to a slice.
+// Gradient slabs: H x H rows straight from the accumulators (each wave owns its rows: plain stores); small parameters via LDS.
+GPE_DEV void row_reduce4_add(const float (&v)[4], float* dst16, int m, int q) {
+    // sum over the 16 point lanes of 4 per-lane values (features 4q+r of the slice); total of value r lands on lanes m>>2 == r
+    const bool b3 = (m & 8) != 0, b2 = (m & 4) != 0;
+    float a2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float lo = v[i] + dpp_mov<0x140>(v[i]), hi = v[i + 2] + dpp_mov<0x140>(v[i + 2]);
+        a2[i] = b3 ? hi : lo;
+    }
+    const float lo = a2[0] + dpp_mov<0x141>(a2[0]), hi = a2[1] + dpp_mov<0x141>(a2[1]);
+    float t = b2 ? hi : lo;
+    t += dpp_mov<0x4E>(t);
+    t += dpp_mov<0xB1>(t);
+    if ((m & 3) == 0) atomicAdd(&dst16[4 * q + (m >> 2)], t);
+}
+
+template <int H, int C, int E, int NOUT, int NHH>
+__global__ __launch_bounds__(H * 4, 2) void f_backward_coop(NetDesc nd, const float* __restrict__ theta,
+                                                            const float* __restrict__ WpkT, const float* __restrict__ x,
+                                                            const float* __restrict__ stored, const float* __restrict__ Ob,
+                                                            float* __restrict__ gslab, int64_t N, int64_t ld, int Ppad) {
+    constexpr int D = C - 1 - E, NT = H / 16, NTHR = 64 * NT;
+    constexpr int L = NHH + 1;                       // index of the output map; hidden layers 0..L-1
+    static_assert(H * 4 == NTHR, "one wave per 16-feature slice");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // LDS: gsm (small-parameter gradients) | g0[4][H] | w0s small operands | ZB[C][NT][256] | XT[C][NT][F_TILE] | TT[NT][C][F_TILE]
+    const int n_gsm = (L - 1 + NOUT) * H + 4;        // b_1..b_{L-1} | W_out[NOUT][H] | b_out
+    float* gsm = lds;
+    float* g0 = gsm + ((n_gsm + 3) & ~3);
+    float* w0s = g0 + 4 * H;
+    float* ZB = w0s + ((small_count(nd, H) + 3) & ~3);
+    float* XT = ZB + C * NT * 256;
+    const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4, w = threadIdx.x >> 6;
+    float* TT = XT + C * NT * F_TILE + w * (C * F_TILE);
+    const int dim = nd.dim;
+    const float shift = nd.shift;
+    const int64_t ntiles = (N + 15) >> 4;
+    const float* Wo = w0s + (4 + L - 1) * H;
+
+    for (int i = threadIdx.x; i < ((n_gsm + 3) & ~3) + 4 * H; i += NTHR) gsm[i] = 0.f;      // gsm and g0 are contiguous
+    stage_layer0<H>(w0s, theta, nd, NTHR);
+    // this wave's K-slices of the transposed weights: A operands of  abar[16w..] = sum_nt W_j^T[16w.., 16nt..] z[16nt..]
+    f32x4 wreg[NHH][NT];
+#pragma unroll
+    for (int a = 0; a < NHH; ++a)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            wreg[a][nt] = *reinterpret_cast<const f32x4*>(&WpkT[(size_t)a * H * H + ((w * NT + nt) * 64 + lane) * 4]);
+    f32x4 dwacc[NHH][NT];                              // rows 16w..16w+15 of dW_j, column tile kt
+#pragma unroll
+    for (int a = 0; a < NHH; ++a)
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) dwacc[a][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t pm = tile * 16 + m;
+        const bool valid = pm < N;
+        const int64_t pl = valid ? pm : N - 1;
+        float xv[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) if (k < dim) xv[k] = x[pl * dim + k];
+        float ob[NOUT][C];
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+            for (int c = 0; c < C; ++c) ob[o][c] = valid ? Ob[((int64_t)c * NOUT + o) * ld + pm] : 0.f;
+        // stored (t, z_k, z_L) of hidden layer h, this wave's feature slice
+        auto load_st = [&](int h, f32x4 (&st)[C]) {
+            if (h >= 1) {
+                const float* sp = stored + ((((size_t)tile * (L - 1) + (h - 1)) * C) * NT + w) * 256 + lane * 4;
+#pragma unroll
+                for (int c = 0; c < C; ++c) st[c] = *reinterpret_cast<const f32x4*>(sp + (size_t)c * NT * 256);
+            } else {
+                layer0_st<H, C, E>(w0s, xv, w, q, st);
+            }
+        };
+        // ---- output layer, own slice ----------------------------------------------------------------------------------
+        f32x4 zb[C];
+        {
+            f32x4 st[C];
+            load_st(L - 1, st);
+            f32x4 wo[NOUT];
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) wo[o] = *reinterpret_cast<const f32x4*>(&Wo[o * H + 16 * w + 4 * q]);
+            float gwo[NOUT][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float zk[D > 0 ? D : 1], zkk[E > 0 ? E : 1], a[C], ab[C], zv[C];
+#pragma unroll
+                for (int jd = 0; jd < D; ++jd) zk[jd] = st[1 + jd][r];
+#pragma unroll
+                for (int e = 0; e < E; ++e) zkk[e] = st[1 + D + e][r];
+                act_from_stored<D, E>(st[0][r], zk, zkk, shift, a);
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) {
+                    float g = 0.f;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) g = fmaf(ob[o][c], a[c], g);
+                    gwo[o][r] = g;
+                }
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int o = 0; o < NOUT; ++o) v = fmaf(wo[o][r], ob[o][c], v);
+                    ab[c] = v;
+                }
+                act_adjoint<D, E>(st[0][r], zk, zkk, ab, zv);
+#pragma unroll
+                for (int c = 0; c < C; ++c) zb[c][r] = zv[c];
+            }
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) row_reduce4_add(gwo[o], &gsm[(L - 1 + o) * H + 16 * w], m, q);
+            if (w == 0) {
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) {
+                    const float gbo = row_sum16(ob[o][0]);
+                    if (lane == 0) atomicAdd(&gsm[(L - 1 + NOUT) * H + o], gbo);
+                }
+            }
+        }
+        // ---- hidden -> hidden maps j = NHH .. 1 ---------------------------------------------------------------------------
+#pragma unroll
+        for (int j = NHH; j >= 1; --j) {
+            {   // bias gradient of map j, own slice
+                const float z0[4] = {zb[0][0], zb[0][1], zb[0][2], zb[0][3]};
+                row_reduce4_add(z0, &gsm[(j - 1) * H + 16 * w], m, q);
+            }
+            // own slice of z: transposed copy for the weight-gradient products (registers), fragment copy for everybody (LDS)
+            f32x4 zt[C];
+            tiles_transpose<C>(zb, zt, TT, m, q);
+#pragma unroll
+            for (int c = 0; c < C; ++c) *reinterpret_cast<f32x4*>(&ZB[(c * NT + w) * 256 + lane * 4]) = zb[c];
+            f32x4 st[C];
+            load_st(j - 1, st);                                   // in flight across the barrier and the products below
+            __syncthreads();
+            // abar (own slice) = sum_nt W_j^T[slice, nt] z[nt] : C independent accumulator chains
+            f32x4 acc[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 bf[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) bf[c] = *reinterpret_cast<const f32x4*>(&ZB[(c * NT + nt) * 256 + lane * 4]);
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                    for (int c = 0; c < C; ++c)
+                        acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j - 1][nt][s2], bf[c][s2], acc[c], 0, 0, 0);
+            }
+            // recompute X of layer j-1 (own slice), activation adjoint -> z of layer j-1, X^T into the shared buffer
+            f32x4 xa[C];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float zk[D > 0 ? D : 1], zkk[E > 0 ? E : 1], a[C], ab[C], zv[C];
+#pragma unroll
+                for (int jd = 0; jd < D; ++jd) zk[jd] = st[1 + jd][r];
+#pragma unroll
+                for (int e = 0; e < E; ++e) zkk[e] = st[1 + D + e][r];
+                act_from_stored<D, E>(st[0][r], zk, zkk, shift, a);
+#pragma unroll
+                for (int c = 0; c < C; ++c) { xa[c][r] = a[c]; ab[c] = acc[c][r]; }
+                act_adjoint<D, E>(st[0][r], zk, zkk, ab, zv);
+#pragma unroll
+                for (int c = 0; c < C; ++c) zb[c][r] = zv[c];
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) XT[(c * NT + w) * F_TILE + (4 * q + r) * F_PITCH + m] = xa[c][r];
+            __syncthreads();
+            // dW_j[rows of this slice][all columns] += Z^T X : NT independent accumulator chains
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                f32x4 xf[NT];
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt)
+                    xf[kt] = *reinterpret_cast<const f32x4*>(&XT[(c * NT + kt) * F_TILE + m * F_PITCH + 4 * q]);
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                    for (int kt = 0; kt < NT; ++kt)
+                        dwacc[j - 1][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(zt[c][s2], xf[kt][s2], dwacc[j - 1][kt], 0, 0, 0);
+            }
+        }
+        // ---- linear map 0, own slice: g0[k][n] (k < dim: dW0[n][k]; k = 3: db0[n]) ---------------------------------------------
+        {
+            const float z0[4] = {zb[0][0], zb[0][1], zb[0][2], zb[0][3]};
+            row_reduce4_add(z0, &g0[3 * H + 16 * w], m, q);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (k < D || (D == 0 && k < dim)) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = zb[0][r] * xv[k];
+                        if constexpr (C > 1) { if (k < D) v[r] += zb[(1 + k) < C ? (1 + k) : 0][r]; }
+                    }
+                    row_reduce4_add(v, &g0[k * H + 16 * w], m, q);
+                }
+            }
+        }
+    }
+    // ---- slab: H x H rows from the accumulators, the rest from LDS ---------------------------------------------------------
+    float* slab = gslab + (size_t)blockIdx.x * Ppad;
+#pragma unroll
+    for (int a = 0; a < NHH; ++a)
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slab[nd.offW[a + 1] + (16 * w + 4 * q + r) * H + 16 * kt + m] = dwacc[a][kt][r];
+    __syncthreads();
+    for (int i = threadIdx.x; i < (L - 1) * H; i += NTHR) slab[nd.offB[1 + i / H] + i % H] = gsm[i];
+    for (int i = threadIdx.x; i < NOUT * H; i += NTHR) slab[nd.offW[L] + i] = gsm[(L - 1) * H + i];
+    for (int i = threadIdx.x; i < NOUT; i += NTHR) slab[nd.offB[L] + i] = gsm[(L - 1 + NOUT) * H + i];
+    for (int i = threadIdx.x; i < 4 * H; i += NTHR) {
+        const int n = i % H, k = i / H;
+        if (k == 3) slab[nd.offB[0] + n] = g0[i];
+        else if (k < dim) slab[nd.offW[0] + n * dim + k] = g0[i];
+    }
+}
+
 // grad[i] += sum_b gslab[b][i].  Block = 64 parameters x 16 slab groups (1024 threads); fixed summation order, so the
 // slab sum is deterministic for a given grid.
 __global__ __launch_bounds__(1024) void k_grad_reduce(const float* __restrict__ gslab, int nslab, int Ppad, int P,
