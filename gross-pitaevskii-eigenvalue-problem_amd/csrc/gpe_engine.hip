@@ -204,6 +204,7 @@ struct gpe_engine {
     int nslab_g = 16;                             // H = 128: number of global-atomic gradient slabs
     int coop = 1;                                 // cooperative reverse kernel: 0 never, 1 whenever compiled for the shape, -1 by batch size
     int64_t coop_max_tiles = 0;
+    int64_t coop_fwd_max_tiles = 0;               // forward: cooperative kernel for batches up to this many tiles
     int64_t stage_min_tiles = 0;                  // batches with fewer 16-point tiles use the unstaged kernels (latency-bound regime)
     hipStream_t side = nullptr;                   // boundary batch runs here, concurrently with the collocation batch
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -334,8 +335,37 @@ static size_t fused_small_bytes(gpe_engine* e) {       // = small_count() of gpe
 static bool staged_batch(gpe_engine* e, const Batch& b) { return (b.n + 15) / 16 >= e->stage_min_tiles; }
 static size_t fused_fwd_lds(gpe_engine* e, bool staged) { return fused_small_bytes(e) + (e->fwd_wlds && staged ? fused_w_bytes(e) : 0); }
 
+static bool coop_shape(gpe_engine* e);
+static unsigned fused_grid(gpe_engine* e, int64_t n, int waves_per_block, int blocks_per_cu);
+static bool fwd_coop(gpe_engine* e, const Batch& b) {
+    return coop_shape(e) && e->coop != 0 && (b.n + 15) / 16 <= e->coop_fwd_max_tiles;
+}
+template <int HH, int CC, int EE, int NO>
+static void launch_fcoop_no(gpe_engine* e, Batch& b, unsigned grid, size_t lds, int store) {
+#define CARGS e->nd, e->theta, e->Wpk, b.x, b.stored, b.O, b.n, b.ld, store
+    switch (e->nd.n_lin - 2) {
+        case 1: hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, NO, 1>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
+        case 2: hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, NO, 2>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
+        default: hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, NO, 3>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
+    }
+#undef CARGS
+}
 template <int HH, int CC, int EE>
 static void launch_f_forward(gpe_engine* e, Batch& b, unsigned grid, int store) {
+    if constexpr (HH <= 64) {
+        if (fwd_coop(e, b)) {
+            const int NT = HH / 16;
+            const size_t lds = fused_small_bytes(e) + ((size_t)2 * CC * NT * 256 + (size_t)NT * e->nd.n_out * CC * 16) * sizeof(float);
+            const unsigned g = fused_grid(e, b.n, 1, 2);
+#ifdef GPE_FAST_BUILD
+            launch_fcoop_no<HH, CC, EE, 1>(e, b, g, lds, store);
+#else
+            if (e->nd.n_out == 1) launch_fcoop_no<HH, CC, EE, 1>(e, b, g, lds, store);
+            else launch_fcoop_no<HH, CC, EE, 2>(e, b, g, lds, store);
+#endif
+            return;
+        }
+    }
     if constexpr (HH > 64) {
         F_LAUNCH(f_forward, HH, CC, EE, false, grid, 256, fused_fwd_lds(e, false), e->nd, e->theta, e->Wpk, b.x, b.stored, b.O, b.n, b.ld, store);
         return;
@@ -348,7 +378,7 @@ static void launch_f_forward(gpe_engine* e, Batch& b, unsigned grid, int store) 
 // reverse-kernel variant for one batch: 3 = cooperative (a workgroup per tile, a wave per 16-feature slice),
 // 2 = weight gradients in registers (1 wave/SIMD), 1 = 512-thread LDS-weight variant,
 // 0 = plain (LDS-atomic gradients, weights from L2; also the fastest when every wave sees only a tile or two)
-static bool coop_shape(gpe_engine* e) { return e->H <= 64 && e->nd.n_lin - 2 >= 1 && e->nd.n_lin - 2 <= 3; }
+static bool coop_shape(gpe_engine* e) { return e->path == GPE_PATH_FUSED && e->H <= 64 && e->nd.n_lin - 2 >= 1 && e->nd.n_lin - 2 <= 3; }
 static int bwd_kind(gpe_engine* e, const Batch& b) {
     if (coop_shape(e) && e->coop != 0 && (e->coop == 1 || (b.n + 15) / 16 <= e->coop_max_tiles)) return 3;
     if (e->H > 64 || !staged_batch(e, b)) return 0;
@@ -712,6 +742,8 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
             e->coop = envc ? atoi(envc) : 1;          // measured: faster than the per-wave-tile kernels at every batch size
             const char* envm = getenv("GPE_COOP_MAX_TILES");
             e->coop_max_tiles = envm ? atoll(envm) : 0;
+            const char* envf = getenv("GPE_COOP_FWD_MAX_TILES");
+            e->coop_fwd_max_tiles = envf ? atoll(envf) : (int64_t)e->num_cu * 8;   // measured: wins below ~32 768 points, loses 8 % at 1M
             const char* envr = getenv("GPE_RACC");
             e->bwd_racc = (!envr || atoi(envr) != 0) && H <= 64 && (Lh - 1) >= 1 && (Lh - 1) <= 3 &&
                           ((size_t)e->Ppad + 4 * (size_t)H + 4 * (size_t)Cmain * F_TILE) * sizeof(float) + smallb + wb <= 160 * 1024;
