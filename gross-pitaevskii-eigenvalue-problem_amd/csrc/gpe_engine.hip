@@ -531,9 +531,12 @@ static int mlp_forward(gpe_engine* e, Batch& b, bool store) {
     return GPE_OK;
 }
 
-// accumulates into e->grad
-static int mlp_backward(gpe_engine* e, Batch& b) {
-    if (b.n <= 0) return GPE_OK;
+static int bc_join(gpe_engine* e);
+static int launch_tail(gpe_engine* e, bool add_bc);
+// accumulates into e->grad.  close: this is the last reverse pass of the step -- join the boundary batch's side stream, add its
+// gradient and write the exchange tail (folded into the slab reduction on the fused path)
+static int mlp_backward(gpe_engine* e, Batch& b, bool close = false) {
+    if (b.n <= 0) return close ? launch_tail(e, true) : GPE_OK;
     if (e->path == GPE_PATH_FUSED) {
         const int kind = bwd_kind(e, b);
         unsigned grid = kind == 3 ? fused_grid(e, b.n, 1, 2)
@@ -562,8 +565,15 @@ static int mlp_backward(gpe_engine* e, Batch& b) {
 #endif
         if (mark) prof_mark(e, 1, false);
         HIPCHK(e, hipGetLastError());
+        const float* add = nullptr;
+        if (close) {
+            int rc = bc_join(e);
+            if (rc) return rc;
+            if (e->bc_inflight) add = e->grad_bc;
+            e->bc_inflight = false;
+        }
         hipLaunchKernelGGL(k_grad_reduce, dim3(cdiv(e->P, 64)), dim3(1024), 0, e->stream, e->gslab, nred, e->Ppad,
-                           e->P, e->grad);
+                           e->P, e->grad, add, close ? (const double*)e->dsc() : (const double*)nullptr);
     } else {
         const NetDesc& nd = e->nd;
         float* Zb = b.Ob;
@@ -583,6 +593,11 @@ static int mlp_backward(gpe_engine* e, Batch& b) {
                 Zb = nxt;
                 nxt = (nxt == b.A0) ? b.A1 : b.A0;
             }
+        }
+        if (close) {
+            int rc = bc_join(e);
+            if (rc) return rc;
+            if ((rc = launch_tail(e, true))) return rc;
         }
     }
     HIPCHK(e, hipGetLastError());
@@ -1065,15 +1080,14 @@ int gpe_step_backward(gpe_engine* e) {
     if (e->phase != 1) FAIL(e, GPE_ERR_STATE, "step_backward without step_begin");
     int rc;
     if ((rc = launch_seed_pde(e, nullptr, 1))) return rc;
-    if ((rc = mlp_backward(e, e->main))) return rc;
-    if (e->cfg.w_sym != 0.f) {
+    const bool with_sym = e->cfg.w_sym != 0.f;
+    if ((rc = mlp_backward(e, e->main, /*close=*/!with_sym))) return rc;
+    if (with_sym) {
         hipLaunchKernelGGL(k_seed_sym, dim3(cdiv(e->main.n, 256)), dim3(256), 0, e->stream, e->ph, e->sym.O, e->sym.Ob,
                            e->main.n, e->sym.ld);
         HIPCHK(e, hipGetLastError());
-        if ((rc = mlp_backward(e, e->sym))) return rc;
+        if ((rc = mlp_backward(e, e->sym, /*close=*/true))) return rc;
     }
-    if ((rc = bc_join(e))) return rc;
-    if ((rc = launch_tail(e, true))) return rc;
     e->phase = 2;
     return GPE_OK;
 }
@@ -1110,8 +1124,7 @@ int gpe_mse_begin(gpe_engine* e) {
     hipLaunchKernelGGL(k_seed_mse, dim3(head_grid(e, e->mse.n)), dim3(256), 0, e->stream, e->ph, e->mse.x, e->mse_target,
                        e->mse.O, e->mse.Ob, e->dsc() + 2, e->mse.n, e->mse.ld);
     HIPCHK(e, hipGetLastError());
-    if ((rc = mlp_backward(e, e->mse))) return rc;
-    if ((rc = launch_tail(e, false))) return rc;
+    if ((rc = mlp_backward(e, e->mse, /*close=*/true))) return rc;
     e->phase = 3;
     return GPE_OK;
 }
