@@ -183,16 +183,16 @@ def main():
         ach = 2.0 * f_fwd * n_local / bwd_s / 1e12 if bwd_s > 0 else 0.0
         ach_f = f_fwd * n_local / fwd_s / 1e12 if fwd_s > 0 else 0.0
         # HBM bytes per launch of the dominant kernel from the committed PMC run of this same workload
-        # (profiles/r01/traffic_ns_v5.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 1/2-fetch correction applied)
+        # (profiles/r01/traffic_ns_v6.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 1/2-fetch correction applied)
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01", "traffic_ns_v5.json")
+        tpath = os.path.join(ROOT, "profiles", "r01", "traffic_ns_v6.json")
         if args.workload == "ns_2d_4x64" and os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                for k, v in tj["kernels"].items():
-                    if "f_backward" in k:
+                for k, v in tj["kernels"].items():          # the collocation batch's launch is the largest f_backward* entry
+                    if "f_backward" in k and (traffic is None or v["hbm_bytes_per_point"] * n_local > traffic):
                         traffic = v["hbm_bytes_per_point"] * n_local
-                        traffic_src = "profiles/r01/traffic_ns_v5.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                        traffic_src = "profiles/r01/traffic_ns_v6.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
             except Exception:
                 pass
         out = {
@@ -205,7 +205,7 @@ def main():
                        "parallelism": f"dp{world}", "kernel_path": "fused_mfma_f32_16x16x4"},
             "per_gpu_points_per_s": value / world,
             "final_loss": sc["loss"], "final_mu": sc["mu"],
-            "roofline": {"bound": "mfma", "kernel": "f_backward<%d,%d,1> (fused jet reverse pass, %d channels)" % (layers[1], chan, chan),
+            "roofline": {"bound": "mfma", "kernel": "%s<%d,%d,...> (fused jet reverse pass, %d channels)" % ("f_backward_coop" if (layers[1] <= 64 and len(layers) - 3 <= 3) else "f_backward", layers[1], chan, chan),
                          "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": (bmat_pt / 2.0 * (len(layers) - 3) / (len(layers) - 2) + 4.0 * chan + 4.0 * layers[0] + 8.0) * n_local,
