@@ -204,6 +204,7 @@ struct gpe_engine {
     int nslab_g = 16;                             // H = 128: number of global-atomic gradient slabs
     int coop = 1;                                 // cooperative reverse kernel: 0 never, 1 whenever compiled for the shape, -1 by batch size
     int64_t coop_max_tiles = 0;
+    bool coop128 = true;                          // H = 128: use the cooperative reverse kernel (else global-atomic slabs)
     int64_t coop_fwd_max_tiles = 0;               // forward: cooperative kernel for batches up to this many tiles
     int64_t stage_min_tiles = 0;                  // batches with fewer 16-point tiles use the unstaged kernels (latency-bound regime)
     hipStream_t side = nullptr;                   // boundary batch runs here, concurrently with the collocation batch
@@ -378,7 +379,12 @@ static void launch_f_forward(gpe_engine* e, Batch& b, unsigned grid, int store) 
 // reverse-kernel variant for one batch: 3 = cooperative (a workgroup per tile, a wave per 16-feature slice),
 // 2 = weight gradients in registers (1 wave/SIMD), 1 = 512-thread LDS-weight variant,
 // 0 = plain (LDS-atomic gradients, weights from L2; also the fastest when every wave sees only a tile or two)
-static bool coop_shape(gpe_engine* e) { return e->path == GPE_PATH_FUSED && e->H <= 64 && e->nd.n_lin - 2 >= 1 && e->nd.n_lin - 2 <= 3; }
+static bool coop_shape(gpe_engine* e) {
+    if (e->path != GPE_PATH_FUSED) return false;
+    const int maps = e->nd.n_lin - 2;                 // hidden -> hidden maps
+    if (e->H <= 64) return maps >= 1 && maps <= 3;
+    return e->H == 128 && maps >= 1 && maps <= 4 && e->nd.dim <= 2 && e->coop128;    // 8 waves per workgroup, weights streamed from L2
+}
 static int bwd_kind(gpe_engine* e, const Batch& b) {
     if (coop_shape(e) && e->coop != 0 && (e->coop == 1 || (b.n + 15) / 16 <= e->coop_max_tiles)) return 3;
     if (e->H > 64 || !staged_batch(e, b)) return 0;
@@ -396,13 +402,17 @@ static void launch_coop_no(gpe_engine* e, Batch& b, unsigned grid, size_t lds) {
     switch (e->nd.n_lin - 2) {
         case 1: hipLaunchKernelGGL((f_backward_coop<HH, CC, EE, NO, 1>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
         case 2: hipLaunchKernelGGL((f_backward_coop<HH, CC, EE, NO, 2>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
-        default: hipLaunchKernelGGL((f_backward_coop<HH, CC, EE, NO, 3>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
+        case 3: hipLaunchKernelGGL((f_backward_coop<HH, CC, EE, NO, 3>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
+        default:
+            if constexpr (HH == 128)
+                hipLaunchKernelGGL((f_backward_coop<HH, CC, EE, NO, 4>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS);
+            break;
     }
 #undef CARGS
 }
 template <int HH, int CC, int EE>
 static void launch_f_backward_coop(gpe_engine* e, Batch& b, unsigned grid, size_t lds) {
-    if constexpr (HH <= 64) {
+    {
 #ifdef GPE_FAST_BUILD
         launch_coop_no<HH, CC, EE, 1>(e, b, grid, lds);
 #else
@@ -549,7 +559,17 @@ static int mlp_backward(gpe_engine* e, Batch& b, bool close = false) {
         if (e->H != 64 || e->nd.n_out != 1) FAIL(e, GPE_ERR_INVALID, "fast build: only H = 64, n_out = 1 compiled");
         DISPATCH_TRAIN(b, launch_f_backward<64, CC, EE>(e, b, grid, lds));
 #else
-        if (e->H == 128) {
+        if (e->H == 128 && kind == 3) {
+            grid = fused_grid(e, b.n, 1, 1);
+            nred = (int)grid;
+            switch (b.C * 10 + b.E) {
+                case 10: launch_f_backward_coop<128, 1, 0>(e, b, grid, lds); break;
+                case 31: launch_f_backward_coop<128, 3, 1>(e, b, grid, lds); break;
+                case 41: launch_f_backward_coop<128, 4, 1>(e, b, grid, lds); break;
+                default: FAIL(e, GPE_ERR_INVALID, "bad channel pair (%d,%d) for H = 128", b.C, b.E);
+            }
+        }
+        else if (e->H == 128) {
             grid = fused_grid(e, b.n, 4, 1);
             nred = e->nslab_g;
             HIPCHK(e, hipMemsetAsync(e->gslab, 0, (size_t)e->nslab_g * e->Ppad * sizeof(float), e->stream));
@@ -738,7 +758,7 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
               alloc((void**)&e->hist, (size_t)e->cap * sizeof(gpe_scalars)) && alloc((void**)&e->last, sizeof(gpe_scalars)) &&
               alloc((void**)&e->orth_dev, 8 * sizeof(float*));
     if (ok && e->path == GPE_PATH_FUSED) {
-        e->nslab = (H == 128) ? e->nslab_g : e->num_cu * 2;
+        e->nslab = (H == 128) ? std::max(e->nslab_g, e->num_cu) : e->num_cu * 2;     // H = 128: 16 atomic slabs, or one per workgroup (cooperative)
         ok = alloc((void**)&e->Wpk, (size_t)(Lh - 1) * H * H * 4) && alloc((void**)&e->WpkT, (size_t)(Lh - 1) * H * H * 4) &&
              alloc((void**)&e->gslab, (size_t)e->nslab * e->Ppad * 4);
         if (ok) {
@@ -757,6 +777,8 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
             e->coop = envc ? atoi(envc) : 1;          // measured: faster than the per-wave-tile kernels at every batch size
             const char* envm = getenv("GPE_COOP_MAX_TILES");
             e->coop_max_tiles = envm ? atoll(envm) : 0;
+            const char* env8 = getenv("GPE_COOP128");
+            e->coop128 = !env8 || atoi(env8) != 0;
             const char* envf = getenv("GPE_COOP_FWD_MAX_TILES");
             e->coop_fwd_max_tiles = envf ? atoll(envf) : (int64_t)e->num_cu * 8;   // measured: wins below ~32 768 points, loses 8 % at 1M
             const char* envr = getenv("GPE_RACC");
@@ -782,7 +804,12 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
             SETLDS(32, 1, 0, 1); SETLDS(32, 3, 1, 1); SETLDS(32, 4, 1, 1); SETLDS(32, 5, 1, 1);
             SETLDS(32, 1, 0, 2); SETLDS(32, 3, 1, 2); SETLDS(32, 4, 1, 2); SETLDS(32, 5, 1, 2);
 #undef SETLDS
-#define SETLDS128(CC, EE, NO) (void)hipFuncSetAttribute((const void*)f_backward<128, CC, EE, NO, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b)
+#define SETLDS128(CC, EE, NO)                                                                                                  \
+    (void)hipFuncSetAttribute((const void*)f_backward_coop<128, CC, EE, NO, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
+    (void)hipFuncSetAttribute((const void*)f_backward_coop<128, CC, EE, NO, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
+    (void)hipFuncSetAttribute((const void*)f_backward_coop<128, CC, EE, NO, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
+    (void)hipFuncSetAttribute((const void*)f_backward_coop<128, CC, EE, NO, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
+    (void)hipFuncSetAttribute((const void*)f_backward<128, CC, EE, NO, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b)
             SETLDS128(1, 0, 1); SETLDS128(3, 1, 1); SETLDS128(4, 1, 1); SETLDS128(1, 0, 2); SETLDS128(3, 1, 2); SETLDS128(4, 1, 2);
 #undef SETLDS128
 #endif

@@ -833,13 +833,22 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_coop(NetDesc nd, const fl
 
     for (int i = threadIdx.x; i < ((n_gsm + 3) & ~3) + 4 * H; i += NTHR) gsm[i] = 0.f;      // gsm and g0 are contiguous
     stage_layer0<H>(w0s, theta, nd, NTHR);
-    // this wave's K-slices of the transposed weights: A operands of  abar[16w..] = sum_nt W_j^T[16w.., 16nt..] z[16nt..]
-    f32x4 wreg[NHH][NT];
+    // this wave's K-slices of the transposed weights: A operands of  abar[16w..] = sum_nt W_j^T[16w.., 16nt..] z[16nt..].
+    // H <= 64: register-resident for the whole kernel.  H = 128: streamed from L2 in chunks of NTC tiles, the first chunk
+    // requested before the barrier that precedes its use.
+    constexpr bool WREG = (H <= 64);
+    constexpr int NTC = WREG ? NT : 4;
+    const float* wbase = WpkT;
+    auto load_w = [&](int a, int nt) {
+        return *reinterpret_cast<const f32x4*>(&wbase[(size_t)a * H * H + ((w * NT + nt) * 64 + lane) * 4]);
+    };
+    f32x4 wreg[WREG ? NHH : 1][WREG ? NT : 1];
+    if constexpr (WREG) {
 #pragma unroll
-    for (int a = 0; a < NHH; ++a)
+        for (int a = 0; a < NHH; ++a)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-            wreg[a][nt] = *reinterpret_cast<const f32x4*>(&WpkT[(size_t)a * H * H + ((w * NT + nt) * 64 + lane) * 4]);
+            for (int nt = 0; nt < NT; ++nt) wreg[a][nt] = load_w(a, nt);
+    }
     f32x4 dwacc[NHH][NT];                              // rows 16w..16w+15 of dW_j, column tile kt
 #pragma unroll
     for (int a = 0; a < NHH; ++a)
@@ -848,6 +857,8 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_coop(NetDesc nd, const fl
     __syncthreads();
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        // streamed weights: keep the (tile-invariant) loads inside the loop -- hoisted, they would occupy NHH*NT*4 registers
+        if constexpr (!WREG) asm volatile("" : "+s"(wbase));
         const int64_t pm = tile * 16 + m;
         const bool valid = pm < N;
         const int64_t pl = valid ? pm : N - 1;
@@ -917,6 +928,7 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_coop(NetDesc nd, const fl
         // ---- hidden -> hidden maps j = NHH .. 1 ---------------------------------------------------------------------------
 #pragma unroll
         for (int j = NHH; j >= 1; --j) {
+            if constexpr (!WREG) __builtin_amdgcn_sched_barrier(0);
             {   // bias gradient of map j, own slice
                 const float z0[4] = {zb[0][0], zb[0][1], zb[0][2], zb[0][3]};
                 row_reduce4_add(z0, &gsm[(j - 1) * H + 16 * w], m, q);
@@ -928,22 +940,40 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_coop(NetDesc nd, const fl
             for (int c = 0; c < C; ++c) *reinterpret_cast<f32x4*>(&ZB[(c * NT + w) * 256 + lane * 4]) = zb[c];
             f32x4 st[C];
             load_st(j - 1, st);                                   // in flight across the barrier and the products below
+            f32x4 wnext[NTC];
+            if constexpr (!WREG) {
+#pragma unroll
+                for (int i = 0; i < NTC; ++i) wnext[i] = load_w(j - 1, i);
+            }
             __syncthreads();
             // abar (own slice) = sum_nt W_j^T[slice, nt] z[nt] : C independent accumulator chains
             f32x4 acc[C];
 #pragma unroll
             for (int c = 0; c < C; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                f32x4 bf[C];
+            for (int nt0 = 0; nt0 < NT; nt0 += NTC) {
+                f32x4 wv[NTC];
 #pragma unroll
-                for (int c = 0; c < C; ++c) bf[c] = *reinterpret_cast<const f32x4*>(&ZB[(c * NT + nt) * 256 + lane * 4]);
+                for (int i = 0; i < NTC; ++i) wv[i] = WREG ? wreg[WREG ? j - 1 : 0][WREG ? nt0 + i : 0] : wnext[i];
+                if constexpr (!WREG) {
+                    if (nt0 + NTC < NT) {
 #pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2)
+                        for (int i = 0; i < NTC; ++i) wnext[i] = load_w(j - 1, nt0 + NTC + i);
+                    }
+                }
 #pragma unroll
-                    for (int c = 0; c < C; ++c)
-                        acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j - 1][nt][s2], bf[c][s2], acc[c], 0, 0, 0);
+                for (int i = 0; i < NTC; ++i) {
+                    f32x4 bf[C];
+#pragma unroll
+                    for (int c = 0; c < C; ++c) bf[c] = *reinterpret_cast<const f32x4*>(&ZB[(c * NT + nt0 + i) * 256 + lane * 4]);
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                        for (int c = 0; c < C; ++c)
+                            acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i][s2], bf[c][s2], acc[c], 0, 0, 0);
+                }
             }
+            if constexpr (!WREG) __builtin_amdgcn_sched_barrier(0);      // keep the phases' live ranges apart (256-register budget)
             // recompute X of layer j-1 (own slice), activation adjoint -> z of layer j-1, X^T into the shared buffer
             f32x4 xa[C];
 #pragma unroll
@@ -966,18 +996,23 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_coop(NetDesc nd, const fl
                 for (int r = 0; r < 4; ++r) XT[(c * NT + w) * F_TILE + (4 * q + r) * F_PITCH + m] = xa[c][r];
             __syncthreads();
             // dW_j[rows of this slice][all columns] += Z^T X : NT independent accumulator chains
+            if constexpr (!WREG) __builtin_amdgcn_sched_barrier(0);
+            constexpr int KTC = (NT > 4) ? 4 : NT;             // column tiles per chunk: KTC independent accumulator chains
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                f32x4 xf[NT];
+            for (int kt0 = 0; kt0 < NT; kt0 += KTC)
 #pragma unroll
-                for (int kt = 0; kt < NT; ++kt)
-                    xf[kt] = *reinterpret_cast<const f32x4*>(&XT[(c * NT + kt) * F_TILE + m * F_PITCH + 4 * q]);
+                for (int c = 0; c < C; ++c) {
+                    f32x4 xf[KTC];
 #pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2)
+                    for (int i = 0; i < KTC; ++i)
+                        xf[i] = *reinterpret_cast<const f32x4*>(&XT[(c * NT + kt0 + i) * F_TILE + m * F_PITCH + 4 * q]);
 #pragma unroll
-                    for (int kt = 0; kt < NT; ++kt)
-                        dwacc[j - 1][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(zt[c][s2], xf[kt][s2], dwacc[j - 1][kt], 0, 0, 0);
-            }
+                    for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                        for (int i = 0; i < KTC; ++i)
+                            dwacc[j - 1][kt0 + i] =
+                                __builtin_amdgcn_mfma_f32_16x16x4f32(zt[c][s2], xf[i][s2], dwacc[j - 1][kt0 + i], 0, 0, 0);
+                }
         }
         // ---- linear map 0, own slice: g0[k][n] (k < dim: dW0[n][k]; k = 3: db0[n]) ---------------------------------------------
         {
