@@ -204,6 +204,7 @@ struct gpe_engine {
     int nslab_g = 16;                             // H = 128: number of global-atomic gradient slabs
     int coop = 1;                                 // cooperative reverse kernel: 0 never, 1 whenever compiled for the shape, -1 by batch size
     int64_t coop_max_tiles = 0;
+    bool coop_fwd128 = true;
     bool coop128 = true;                          // H = 128: use the cooperative reverse kernel (else global-atomic slabs)
     int64_t coop_fwd_max_tiles = 0;               // forward: cooperative kernel for batches up to this many tiles
     int64_t stage_min_tiles = 0;                  // batches with fewer 16-point tiles use the unstaged kernels (latency-bound regime)
@@ -339,7 +340,9 @@ static size_t fused_fwd_lds(gpe_engine* e, bool staged) { return fused_small_byt
 static bool coop_shape(gpe_engine* e);
 static unsigned fused_grid(gpe_engine* e, int64_t n, int waves_per_block, int blocks_per_cu);
 static bool fwd_coop(gpe_engine* e, const Batch& b) {
-    return coop_shape(e) && e->coop != 0 && (b.n + 15) / 16 <= e->coop_fwd_max_tiles;
+    if (!coop_shape(e) || e->coop == 0) return false;
+    if (e->H == 128) return e->coop_fwd128;           // wide layers: the cooperative forward wins at every size (measured)
+    return (b.n + 15) / 16 <= e->coop_fwd_max_tiles;
 }
 template <int HH, int CC, int EE, int NO>
 static void launch_fcoop_no(gpe_engine* e, Batch& b, unsigned grid, size_t lds, int store) {
@@ -347,17 +350,21 @@ static void launch_fcoop_no(gpe_engine* e, Batch& b, unsigned grid, size_t lds, 
     switch (e->nd.n_lin - 2) {
         case 1: hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, NO, 1>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
         case 2: hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, NO, 2>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
-        default: hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, NO, 3>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
+        case 3: hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, NO, 3>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
+        default:
+            if constexpr (HH == 128)
+                hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, NO, 4>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS);
+            break;
     }
 #undef CARGS
 }
 template <int HH, int CC, int EE>
 static void launch_f_forward(gpe_engine* e, Batch& b, unsigned grid, int store) {
-    if constexpr (HH <= 64) {
+    if constexpr (HH <= 64 || (HH == 128 && CC <= 4)) {
         if (fwd_coop(e, b)) {
             const int NT = HH / 16;
             const size_t lds = fused_small_bytes(e) + ((size_t)2 * CC * NT * 256 + (size_t)NT * e->nd.n_out * CC * 16) * sizeof(float);
-            const unsigned g = fused_grid(e, b.n, 1, 2);
+            const unsigned g = fused_grid(e, b.n, 1, HH == 128 ? 1 : 2);
 #ifdef GPE_FAST_BUILD
             launch_fcoop_no<HH, CC, EE, 1>(e, b, g, lds, store);
 #else
@@ -779,6 +786,8 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
             e->coop_max_tiles = envm ? atoll(envm) : 0;
             const char* env8 = getenv("GPE_COOP128");
             e->coop128 = !env8 || atoi(env8) != 0;
+            const char* env9 = getenv("GPE_COOP_FWD128");
+            e->coop_fwd128 = !env9 || atoi(env9) != 0;
             const char* envf = getenv("GPE_COOP_FWD_MAX_TILES");
             e->coop_fwd_max_tiles = envf ? atoll(envf) : (int64_t)e->num_cu * 8;   // measured: wins below ~32 768 points, loses 8 % at 1M
             const char* envr = getenv("GPE_RACC");
@@ -809,6 +818,10 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
     (void)hipFuncSetAttribute((const void*)f_backward_coop<128, CC, EE, NO, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
     (void)hipFuncSetAttribute((const void*)f_backward_coop<128, CC, EE, NO, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
     (void)hipFuncSetAttribute((const void*)f_backward_coop<128, CC, EE, NO, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
+    (void)hipFuncSetAttribute((const void*)f_forward_coop<128, CC, EE, NO, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
+    (void)hipFuncSetAttribute((const void*)f_forward_coop<128, CC, EE, NO, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
+    (void)hipFuncSetAttribute((const void*)f_forward_coop<128, CC, EE, NO, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
+    (void)hipFuncSetAttribute((const void*)f_forward_coop<128, CC, EE, NO, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
     (void)hipFuncSetAttribute((const void*)f_backward<128, CC, EE, NO, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b)
             SETLDS128(1, 0, 1); SETLDS128(3, 1, 1); SETLDS128(4, 1, 1); SETLDS128(1, 0, 2); SETLDS128(3, 1, 2); SETLDS128(4, 1, 2);
 #undef SETLDS128
