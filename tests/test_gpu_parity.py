@@ -510,12 +510,41 @@ def test_side_stream_and_graph_replay_change_nothing(kw, N):
     assert same(l, base_l) and same(t, base_t)
 
 
-def test_staged_and_unstaged_kernel_variants_agree():
-    """Batches below / above the staging threshold use different fused kernels (weights from L2 + LDS-atomic gradients vs
-    LDS-staged weights + register-resident gradients); one step from the same state must agree to fp32 round-off."""
-    kw = dict(layers=[2, 64, 64, 64, 64, 1], gamma=50.0, dx=0.01)
-    N = 4096
-    la, _, ga = _trajectory({"GPE_STAGE_MIN_TILES": "0"}, kw, N, 1, use_run=False)          # always staged
-    lb, _, gb = _trajectory({"GPE_STAGE_MIN_TILES": "1000000000"}, kw, N, 1, use_run=False)  # never staged
-    assert abs(la[0] - lb[0]) <= 1e-6 * abs(la[0])
-    assert H.rel_err(ga, gb) < 2e-6
+@pytest.mark.parametrize("kw,N,envs", [
+    (dict(layers=[2, 64, 64, 64, 64, 1], gamma=50.0, dx=0.01), 4096,
+     [{"GPE_COOP": "1", "GPE_COOP_FWD_MAX_TILES": "0"}, {"GPE_COOP": "1", "GPE_COOP_FWD_MAX_TILES": "1000000000"},
+      {"GPE_COOP": "0", "GPE_STAGE_MIN_TILES": "0"}, {"GPE_COOP": "0", "GPE_STAGE_MIN_TILES": "1000000000"},
+      {"GPE_COOP": "0", "GPE_STAGE_MIN_TILES": "0", "GPE_RACC": "0"}]),
+    (dict(layers=[1, 32, 32, 32, 1], gamma=5.0, base_mode=0, dx=0.01), 1000,
+     [{"GPE_COOP": "1"}, {"GPE_COOP": "0", "GPE_STAGE_MIN_TILES": "0"}, {"GPE_COOP": "0", "GPE_STAGE_MIN_TILES": "1000000000"}]),
+    (dict(layers=[2, 128, 128, 128, 1], gamma=50.0, dx=0.01), 777,
+     [{"GPE_COOP128": "1", "GPE_COOP_FWD128": "1"}, {"GPE_COOP128": "0", "GPE_COOP_FWD128": "0"},
+      {"GPE_COOP128": "1", "GPE_COOP_FWD128": "0"}]),
+])
+def test_kernel_variants_agree(kw, N, envs):
+    """The fused path has several kernels for the same two primitives -- cooperative (a workgroup per tile), per-wave-tile with
+    LDS-staged weights + register-resident gradients, per-wave-tile unstaged with LDS-atomic gradients, global-atomic slabs for
+    H = 128 -- selected by shape and batch size.  One step from the same state must agree to fp32 round-off whichever runs."""
+    scale = 0.15 if max(kw["layers"][1:-1]) > 64 else 0.3
+    ref = None
+    for env in envs:
+        import os
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            x, flat, x_bc = _inputs(kw, N, scale=scale)
+            eng = make_engine(go.Problem(**kw), flat, x, x_bc)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        sc = eng.step()
+        g = eng.get_grad()
+        eng.close()
+        if ref is None:
+            ref = (sc["loss"], g)
+        else:
+            assert abs(sc["loss"] - ref[0]) <= 2e-6 * abs(ref[0]), env
+            assert H.rel_err(g, ref[1]) < 3e-6, env
