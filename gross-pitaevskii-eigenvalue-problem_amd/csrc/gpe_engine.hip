@@ -199,7 +199,7 @@ struct gpe_engine {
     int nslab = 0;
     bool packed_dirty = true;
     bool ext_exchange = false;
-    bool fwd_wlds = false, bwd_wlds = false;      // hidden-hidden weights staged in LDS by the fused kernels
+    bool fwd_wlds = false;                        // forward kernel stages the hidden-hidden weights in LDS
     bool bwd_racc = false;                        // reverse kernel keeps the H x H weight gradients in registers (1 wave/SIMD)
     int nslab_g = 16;                             // H = 128: number of global-atomic gradient slabs
     int coop = 1;                                 // cooperative reverse kernel: 0 never, 1 whenever compiled for the shape, -1 by batch size
@@ -384,7 +384,7 @@ static void launch_f_forward(gpe_engine* e, Batch& b, unsigned grid, int store) 
         F_LAUNCH(f_forward, HH, CC, EE, false, grid, 256, fused_fwd_lds(e, false), e->nd, e->theta, e->Wpk, b.x, b.stored, b.O, b.n, b.ld, store);
 }
 // reverse-kernel variant for one batch: 3 = cooperative (a workgroup per tile, a wave per 16-feature slice),
-// 2 = weight gradients in registers (1 wave/SIMD), 1 = 512-thread LDS-weight variant,
+// 2 = weight gradients in registers (1 wave/SIMD),
 // 0 = plain (LDS-atomic gradients, weights from L2; also the fastest when every wave sees only a tile or two)
 static bool coop_shape(gpe_engine* e) {
     if (e->path != GPE_PATH_FUSED) return false;
@@ -395,7 +395,7 @@ static bool coop_shape(gpe_engine* e) {
 static int bwd_kind(gpe_engine* e, const Batch& b) {
     if (coop_shape(e) && e->coop != 0 && (e->coop == 1 || (b.n + 15) / 16 <= e->coop_max_tiles)) return 3;
     if (e->H > 64 || !staged_batch(e, b)) return 0;
-    return e->bwd_racc ? 2 : (e->bwd_wlds ? 1 : 0);
+    return e->bwd_racc ? 2 : 0;
 }
 static size_t coop_lds(gpe_engine* e, int C) {
     const int H = e->H, NT = H / 16, L = e->nd.n_lin - 1;
@@ -443,8 +443,7 @@ static void launch_f_backward(gpe_engine* e, Batch& b, unsigned grid, size_t lds
             case 2: B_LAUNCH(HH, CC, EE, true, 2, grid, 256, lds, BARGS); break;
             default: B_LAUNCH(HH, CC, EE, true, 3, grid, 256, lds, BARGS); break;
         }
-    } else if (kind == 1)
-        B_LAUNCH(HH, CC, EE, true, 0, grid, 512, lds, BARGS);
+    }
     else
         B_LAUNCH(HH, CC, EE, false, 0, grid, 256, lds, BARGS);
 #undef BARGS
@@ -463,7 +462,7 @@ static unsigned fused_grid(gpe_engine* e, int64_t n, int waves_per_block, int bl
 
 static size_t fused_bwd_lds(gpe_engine* e, int C, int kind) {
     if (e->H > 64) return ((size_t)4 * e->H + (size_t)4 * C * F_TILE) * sizeof(float) + fused_small_bytes(e);
-    const int nwaves = kind == 1 ? 8 : 4;
+    const int nwaves = 4;
     const bool w = kind != 0;
     return ((size_t)e->Ppad + 4 * (size_t)e->H + (size_t)nwaves * C * F_TILE) * sizeof(float) + fused_small_bytes(e) +
            (w ? fused_w_bytes(e) : 0);
@@ -557,7 +556,7 @@ static int mlp_backward(gpe_engine* e, Batch& b, bool close = false) {
     if (e->path == GPE_PATH_FUSED) {
         const int kind = bwd_kind(e, b);
         unsigned grid = kind == 3 ? fused_grid(e, b.n, 1, 2)
-                                  : (kind == 2 ? fused_grid(e, b.n, 4, 1) : (kind == 1 ? fused_grid(e, b.n, 8, 1) : fused_grid(e, b.n, 4, 2)));
+                                  : (kind == 2 ? fused_grid(e, b.n, 4, 1) : fused_grid(e, b.n, 4, 2));
         size_t lds = kind == 3 ? coop_lds(e, b.C) : fused_bwd_lds(e, b.C, kind);
         const bool mark = e->prof && (&b == &e->main);
         if (mark) prof_mark(e, 1, true);
@@ -775,11 +774,6 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
             const bool want = env ? (atoi(env) != 0) : true;
             const size_t smallb = ((size_t)(4 + (Lh - 1) + no) * H + 8) * sizeof(float);
             e->fwd_wlds = want && H <= 64 && wb + smallb <= 64 * 1024;
-            // reverse kernel: measured slower with 512-thread workgroups + LDS weights (5.40 vs 5.29 ms on NS): opt-in only
-            e->bwd_wlds = want && H <= 64 && (!env || atoi(env) != 3) &&
-                          ((size_t)e->Ppad + 4 * (size_t)H + 8 * (size_t)Cmain * F_TILE) * sizeof(float) + smallb + wb <= 160 * 1024;
-            const char* envs = getenv("GPE_STAGE_MIN_TILES");
-            e->stage_min_tiles = envs ? atoll(envs) : (int64_t)e->num_cu * 8;   // measured crossover: 2 tiles per wave at 1 wave/SIMD
             const char* envc = getenv("GPE_COOP");
             e->coop = envc ? atoi(envc) : 1;          // measured: faster than the per-wave-tile kernels at every batch size
             const char* envm = getenv("GPE_COOP_MAX_TILES");
@@ -797,7 +791,6 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
             const int lds_b = 160 * 1024, lds_f = 64 * 1024;
 #define SETLDS(HH, CC, EE, NO)                                                                                                   \
     (void)hipFuncSetAttribute((const void*)f_backward<HH, CC, EE, NO, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
-    (void)hipFuncSetAttribute((const void*)f_backward<HH, CC, EE, NO, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);  \
     (void)hipFuncSetAttribute((const void*)f_backward<HH, CC, EE, NO, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);  \
     (void)hipFuncSetAttribute((const void*)f_backward<HH, CC, EE, NO, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);  \
     (void)hipFuncSetAttribute((const void*)f_backward<HH, CC, EE, NO, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);  \
