@@ -34,6 +34,9 @@ WORKLOADS = {
     "ns_2d_4x64": dict(layers=[2, 64, 64, 64, 64, 1], grid=(1024, 1024), gamma=500.0, half=8.0),
     "cfg2_1d_4x64": dict(layers=[1, 64, 64, 64, 64, 1], grid=(65536,), gamma=100.0, half=10.0),
     "cfg3_2d_5x128": dict(layers=[2, 128, 128, 128, 128, 128, 1], grid=(512, 256), gamma=500.0, half=8.0),
+    # BASELINE configs[3]: rotating trap, complex psi (n_out = 2), 6x128; 2 097 152 points over 8 GPUs = 262 144 per GPU
+    "cfg4_2d_6x128_rot": dict(layers=[2, 128, 128, 128, 128, 128, 128, 2], grid=(512, 512), gamma=500.0, half=8.0,
+                              complex_psi=True, omega_rot=0.8),
 }
 
 
@@ -78,7 +81,8 @@ def cpu_baseline(wl, flat, budget_s=12.0, n_sample=8192):
     idx = np.linspace(0, x.shape[0] - 1, n_sample).astype(np.int64)
     xs = x[idx]
     pb = go.Problem(layers=wl["layers"], gamma=wl["gamma"], p=3, kinetic_coeff=0.5, pot_scale=0.5, dx=dx,
-                    w_bc=10.0, w_norm=20.0)
+                    w_bc=10.0, w_norm=20.0, complex_psi=bool(wl.get("complex_psi", False)),
+                    omega_rot=float(wl.get("omega_rot", 0.0)))
     trn = tr.TorchTrainer(pb, flat, xs, xb, lr=1e-3, sched=go.SCHED_CONST)
     ncpu = os.cpu_count() or 1
     best = None
@@ -133,7 +137,8 @@ def main():
     x, dx, xb = make_points(wl, rank, world)
     n_local = x.shape[0]
     cfg = gpe_pinn.GPEConfig(layers=layers, gamma=wl["gamma"], p=3, kinetic_coeff=0.5, pot_scale=0.5, dx=dx,
-                             w_bc=10.0, w_norm=20.0, lr=1e-3, n_global=n_local * world, world_size=world)
+                             w_bc=10.0, w_norm=20.0, lr=1e-3, n_global=n_local * world, world_size=world,
+                             complex_psi=bool(wl.get("complex_psi", False)), omega_rot=float(wl.get("omega_rot", 0.0)))
     eng = gpe_pinn.Engine(cfg, device=local_rank)
     if eng.active_path != gpe_pinn.PATH_FUSED:
         raise SystemExit("bench: fused MFMA path not active")
@@ -205,7 +210,7 @@ def main():
                        "parallelism": f"dp{world}", "kernel_path": "fused_mfma_f32_16x16x4"},
             "per_gpu_points_per_s": value / world,
             "final_loss": sc["loss"], "final_mu": sc["mu"],
-            "roofline": {"bound": "mfma", "kernel": "%s<%d,%d,...> (fused jet reverse pass, %d channels)" % ("f_backward_coop" if (layers[1] <= 64 and len(layers) - 3 <= 3) else "f_backward", layers[1], chan, chan),
+            "roofline": {"bound": "mfma", "kernel": "%s<%d,%d,...> (fused jet reverse pass, %d channels)" % ("f_backward_coop" if ((layers[1] <= 64 and len(layers) - 3 <= 3) or (layers[1] == 128 and len(layers) - 3 <= 5 and layers[0] <= 2)) else "f_backward", layers[1], chan, chan),
                          "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": (bmat_pt / 2.0 * (len(layers) - 3) / (len(layers) - 2) + 4.0 * chan + 4.0 * layers[0] + 8.0) * n_local,

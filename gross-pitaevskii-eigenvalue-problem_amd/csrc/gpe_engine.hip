@@ -351,9 +351,13 @@ static void launch_fcoop_no(gpe_engine* e, Batch& b, unsigned grid, size_t lds, 
         case 1: hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, NO, 1>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
         case 2: hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, NO, 2>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
         case 3: hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, NO, 3>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
-        default:
+        case 4:
             if constexpr (HH == 128)
                 hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, NO, 4>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS);
+            break;
+        default:
+            if constexpr (HH == 128)
+                hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, NO, 5>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS);
             break;
     }
 #undef CARGS
@@ -390,7 +394,7 @@ static bool coop_shape(gpe_engine* e) {
     if (e->path != GPE_PATH_FUSED) return false;
     const int maps = e->nd.n_lin - 2;                 // hidden -> hidden maps
     if (e->H <= 64) return maps >= 1 && maps <= 3;
-    return e->H == 128 && maps >= 1 && maps <= 4 && e->nd.dim <= 2 && e->coop128;    // 8 waves per workgroup, weights streamed from L2
+    return e->H == 128 && maps >= 1 && maps <= 5 && e->nd.dim <= 2 && e->coop128;    // 8 waves per workgroup, weights streamed from L2
 }
 static int bwd_kind(gpe_engine* e, const Batch& b) {
     if (coop_shape(e) && e->coop != 0 && (e->coop == 1 || (b.n + 15) / 16 <= e->coop_max_tiles)) return 3;
@@ -410,9 +414,13 @@ static void launch_coop_no(gpe_engine* e, Batch& b, unsigned grid, size_t lds) {
         case 1: hipLaunchKernelGGL((f_backward_coop<HH, CC, EE, NO, 1>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
         case 2: hipLaunchKernelGGL((f_backward_coop<HH, CC, EE, NO, 2>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
         case 3: hipLaunchKernelGGL((f_backward_coop<HH, CC, EE, NO, 3>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
-        default:
+        case 4:
             if constexpr (HH == 128)
                 hipLaunchKernelGGL((f_backward_coop<HH, CC, EE, NO, 4>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS);
+            break;
+        default:
+            if constexpr (HH == 128)
+                hipLaunchKernelGGL((f_backward_coop<HH, CC, EE, NO, 5>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS);
             break;
     }
 #undef CARGS
@@ -811,6 +819,8 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
     (void)hipFuncSetAttribute((const void*)f_backward_coop<128, CC, EE, NO, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
     (void)hipFuncSetAttribute((const void*)f_backward_coop<128, CC, EE, NO, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
     (void)hipFuncSetAttribute((const void*)f_backward_coop<128, CC, EE, NO, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
+    (void)hipFuncSetAttribute((const void*)f_backward_coop<128, CC, EE, NO, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
+    (void)hipFuncSetAttribute((const void*)f_forward_coop<128, CC, EE, NO, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
     (void)hipFuncSetAttribute((const void*)f_forward_coop<128, CC, EE, NO, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
     (void)hipFuncSetAttribute((const void*)f_forward_coop<128, CC, EE, NO, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
     (void)hipFuncSetAttribute((const void*)f_forward_coop<128, CC, EE, NO, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \

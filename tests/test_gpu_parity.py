@@ -65,6 +65,8 @@ CASES = {
     "2d_128x3_cfg3like": (dict(layers=[2, 128, 128, 128, 1], gamma=100.0, dx=0.01), 300, True),
     "2d_128x5_cfg3": (dict(layers=[2, 128, 128, 128, 128, 128, 1], gamma=500.0, dx=0.01), 200, True),
     "2d_128x6_complex_cfg4like": (dict(layers=[2, 128, 128, 2], complex_psi=True, gamma=50.0, omega_rot=0.8, dx=0.01), 150, True),
+    "2d_128x6_complex_cfg4": (dict(layers=[2, 128, 128, 128, 128, 128, 128, 2], complex_psi=True, gamma=50.0, omega_rot=0.8,
+                                   dx=0.01), 150, True),
     "1d_128x2": (dict(layers=[1, 128, 128, 1], gamma=5.0, base_mode=0, dx=0.02), 130, True),
     "3d_256x2_cfg5like": (dict(layers=[3, 256, 256, 1], gamma=100.0, dx=0.01, omega=(1.0, 1.4, 2.0)), 64, False),
     "2d_100x2_odd_width": (dict(layers=[2, 100, 100, 1], gamma=1.0, dx=0.01), 77, False),
