@@ -54,7 +54,9 @@ __global__ __launch_bounds__(1024) void k_update(int P, float* __restrict__ thet
                                                   const double* __restrict__ sums, const double* __restrict__ lsums,
                                                   Phys ph, OptCfg oc, OptDev* __restrict__ od,
                                                   gpe_scalars* __restrict__ hist, int cap, gpe_scalars* __restrict__ last,
-                                                  double bc_cnt, int do_update, int mse_mode) {
+                                                  double bc_cnt, int do_update, int mse_mode, NetDesc nd, int H,
+                                                  float* __restrict__ Wpk, float* __restrict__ WpkT, int n_pack,
+                                                  double* __restrict__ dbl, int n_dbl) {
     __shared__ double red[16];
     __shared__ float s_coef, s_ss, s_b2s;
     __shared__ int s_skip;
@@ -139,18 +141,24 @@ __global__ __launch_bounds__(1024) void k_update(int P, float* __restrict__ thet
         }
     }
     __syncthreads();
-    if (s_skip) return;
-    const float coef = s_coef, ss = s_ss, b2s = s_b2s;
-    const float b1 = oc.beta1, b2 = oc.beta2, eps = oc.eps;
-    for (int i = threadIdx.x; i < P; i += 1024) {
-        float g = grad[i] * coef;
-        float m = am[i], v = av[i];
-        m = m + (g - m) * (1.0f - b1);                 // exp_avg.lerp_(grad, 1-beta1)
-        v = v * b2 + (1.0f - b2) * g * g;              // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1-beta2)
-        float denom = sqrtf(v) / b2s + eps;
-        theta[i] = theta[i] - ss * (m / denom);        // param.addcdiv_(exp_avg, denom, value=-step_size)
-        am[i] = m; av[i] = v;
+    if (!s_skip) {
+        const float coef = s_coef, ss = s_ss, b2s = s_b2s;
+        const float b1 = oc.beta1, b2 = oc.beta2, eps = oc.eps;
+        for (int i = threadIdx.x; i < P; i += 1024) {
+            float g = grad[i] * coef;
+            float m = am[i], v = av[i];
+            m = m + (g - m) * (1.0f - b1);                 // exp_avg.lerp_(grad, 1-beta1)
+            v = v * b2 + (1.0f - b2) * g * g;              // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1-beta2)
+            float denom = sqrtf(v) / b2s + eps;
+            theta[i] = theta[i] - ss * (m / denom);        // param.addcdiv_(exp_avg, denom, value=-step_size)
+            am[i] = m; av[i] = v;
+        }
     }
+    // Prepare the NEXT step, so that it can start with its forward kernel: the step sums are consumed (thread 0 read them
+    // before the barrier above) -> zero them; repack the hidden-hidden weights in MFMA fragment order from the new parameters.
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_dbl; i += 1024) dbl[i] = 0.0;
+    for (int i = threadIdx.x; i < n_pack; i += 1024) pack_weight_element(nd, H, theta, Wpk, WpkT, i);
 }
 
 // closes the reverse phase: adds the boundary-batch gradient (computed on the side stream) and fills the exchange tail
@@ -198,6 +206,7 @@ struct gpe_engine {
     float *Wpk = nullptr, *WpkT = nullptr, *gslab = nullptr;
     int nslab = 0;
     bool packed_dirty = true;
+    bool acc_clean = false;                       // step sums are zero (left so by k_update): the next step needs no k_begin
     bool ext_exchange = false;
     bool fwd_wlds = false;                        // forward kernel stages the hidden-hidden weights in LDS
     bool bwd_racc = false;                        // reverse kernel keeps the H x H weight gradients in registers (1 wave/SIMD)
@@ -488,7 +497,10 @@ static int ensure_packed(gpe_engine* e) {
 }
 
 // zero the step accumulators (+ repack weights when stale) in one launch
-static int launch_begin(gpe_engine* e) {
+static int launch_begin(gpe_engine* e, bool force = false) {
+    // fused path: k_update zeroed the sums and repacked the weights, and the first slab reduction assigns -> nothing to do
+    if (!force && e->path == GPE_PATH_FUSED && e->acc_clean && !e->packed_dirty) { e->acc_clean = false; return GPE_OK; }
+    e->acc_clean = false;
     int n_pack = 0;
     if (e->path == GPE_PATH_FUSED && e->packed_dirty) n_pack = (e->nd.n_lin - 2) * e->H * e->H;
     const int n_dbl = S_COUNT + LS_COUNT + 4, n_grad = e->P + GT_COUNT, n_bc = e->P;
@@ -557,9 +569,9 @@ static int mlp_forward(gpe_engine* e, Batch& b, bool store) {
 
 static int bc_join(gpe_engine* e);
 static int launch_tail(gpe_engine* e, bool add_bc);
-// accumulates into e->grad.  close: this is the last reverse pass of the step -- join the boundary batch's side stream, add its
+// Gradient of one batch into e->grad: assigned (first reverse pass of the step) or accumulated.  close: this is the last reverse pass of the step -- join the boundary batch's side stream, add its
 // gradient and write the exchange tail (folded into the slab reduction on the fused path)
-static int mlp_backward(gpe_engine* e, Batch& b, bool close = false) {
+static int mlp_backward(gpe_engine* e, Batch& b, bool close = false, bool assign = true) {
     if (b.n <= 0) return close ? launch_tail(e, true) : GPE_OK;
     if (e->path == GPE_PATH_FUSED) {
         const int kind = bwd_kind(e, b);
@@ -607,7 +619,7 @@ static int mlp_backward(gpe_engine* e, Batch& b, bool close = false) {
             e->bc_inflight = false;
         }
         hipLaunchKernelGGL(k_grad_reduce, dim3(cdiv(e->P, 64)), dim3(1024), 0, e->stream, e->gslab, nred, e->Ppad,
-                           e->P, e->grad, add, close ? (const double*)e->dsc() : (const double*)nullptr);
+                           e->P, e->grad, add, close ? (const double*)e->dsc() : (const double*)nullptr, assign ? 1 : 0);
     } else {
         const NetDesc& nd = e->nd;
         float* Zb = b.Ob;
@@ -694,6 +706,7 @@ int gpe_use_external_exchange(gpe_engine* e, void* d_dbl, int64_t n_dbl, void* d
     HIPCHK(e, hipStreamSynchronize(e->stream));
     if (!e->ext_exchange) { (void)hipFree(e->dbl); (void)hipFree(e->grad); }
     e->dbl = (double*)d_dbl; e->grad = (float*)d_grad; e->ext_exchange = true;
+    e->acc_clean = false;                        // caller-owned buffers: the next step starts with k_begin
     return GPE_OK;
 }
 
@@ -1020,6 +1033,7 @@ int gpe_eval_density(gpe_engine* e, const float* d_x, int64_t n, float dx, int a
     int rc = aux_forward(e, d_x, n, 1, 0);
     if (rc) return rc;
     double* acc = e->dsc() + 1;
+    e->acc_clean = false;
     HIPCHK(e, hipMemsetAsync(acc, 0, sizeof(double), e->stream));
     hipLaunchKernelGGL(k_eval_u, dim3(cdiv(n, 256)), dim3(256), 0, e->stream, e->ph, e->base_norm, d_x, e->aux.O, e->aux.u,
                        acc, n, e->aux.ld);
@@ -1129,21 +1143,28 @@ int gpe_step_backward(gpe_engine* e) {
         hipLaunchKernelGGL(k_seed_sym, dim3(cdiv(e->main.n, 256)), dim3(256), 0, e->stream, e->ph, e->sym.O, e->sym.Ob,
                            e->main.n, e->sym.ld);
         HIPCHK(e, hipGetLastError());
-        if ((rc = mlp_backward(e, e->sym, /*close=*/true))) return rc;
+        if ((rc = mlp_backward(e, e->sym, /*close=*/true, /*assign=*/false))) return rc;
     }
     e->phase = 2;
     return GPE_OK;
 }
 
+// trailing arguments of k_update: what it needs to prepare the next step (weight packing on the fused path, sum zeroing)
+#define UPD_TAIL_ARGS e->nd, e->H, e->Wpk, e->WpkT, (e->path == GPE_PATH_FUSED ? (e->nd.n_lin - 2) * e->H * e->H : 0), e->dbl, \
+                      (int)(S_COUNT + LS_COUNT + 4)
+static void after_update(gpe_engine* e) {          // host-side mirror of what k_update left behind
+    e->acc_clean = true;
+    e->packed_dirty = false;
+}
 static double bc_count(gpe_engine* e) { return (e->bc.n > 0 && e->cfg.w_bc != 0.f) ? (double)e->bc.n * e->nd.n_out : 0.0; }
 
 int gpe_step_update(gpe_engine* e) {
     if (!e) return GPE_ERR_INVALID;
     if (e->phase != 2) FAIL(e, GPE_ERR_STATE, "step_update without step_backward");
     hipLaunchKernelGGL(k_update, dim3(1), dim3(1024), 0, e->stream, e->P, e->theta, e->am, e->av, e->grad, e->sums(),
-                       e->lsums(), e->ph, e->oc, e->od, e->hist, e->cap, e->last, bc_count(e), 1, 0);
+                       e->lsums(), e->ph, e->oc, e->od, e->hist, e->cap, e->last, bc_count(e), 1, 0, UPD_TAIL_ARGS);
     HIPCHK(e, hipGetLastError());
-    e->packed_dirty = true;
+    after_update(e);
     e->phase = 0;
     return GPE_OK;
 }
@@ -1176,9 +1197,9 @@ static int mse_finish(gpe_engine* e, int do_update) {
     if (e->phase != 3) FAIL(e, GPE_ERR_STATE, "mse update without mse begin");
     // sums[S_DEN] must be non-zero for the (unused) Rayleigh quotient of the shared update kernel
     hipLaunchKernelGGL(k_update, dim3(1), dim3(1024), 0, e->stream, e->P, e->theta, e->am, e->av, e->grad, e->sums(),
-                       e->lsums(), e->ph, e->oc, e->od, e->hist, e->cap, e->last, 0.0, do_update, 1);
+                       e->lsums(), e->ph, e->oc, e->od, e->hist, e->cap, e->last, 0.0, do_update, 1, UPD_TAIL_ARGS);
     HIPCHK(e, hipGetLastError());
-    if (do_update) e->packed_dirty = true;
+    after_update(e);
     e->phase = 0;
     return GPE_OK;
 }
@@ -1273,7 +1294,8 @@ static int graph_build(gpe_engine* e) {
     std::vector<char> key = graph_key_of(e);
     hipStream_t s0 = e->stream;
     e->stream = e->cap_stream;
-    e->packed_dirty = true;                       // every replayed step starts from freshly updated parameters
+    e->packed_dirty = true;                       // the captured step always starts with k_begin
+    e->acc_clean = false;
     hipGraph_t g = nullptr;
     int rc = GPE_OK;
     if (hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { e->stream = s0; return GPE_ERR_HIP; }
@@ -1281,7 +1303,8 @@ static int graph_build(gpe_engine* e) {
     hipError_t st = hipStreamEndCapture(e->cap_stream, &g);
     e->stream = s0;
     e->phase = 0;
-    e->packed_dirty = true;
+    e->packed_dirty = true;                       // nothing ran during capture
+    e->acc_clean = false;
     if (rc || st != hipSuccess || !g) { if (g) (void)hipGraphDestroy(g); (void)hipGetLastError(); return rc ? rc : GPE_ERR_HIP; }
     st = hipGraphInstantiate(&e->graph_exec, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
@@ -1298,7 +1321,7 @@ int gpe_run(gpe_engine* e, int64_t n_steps) {
         }
         if (e->graph_exec) {
             for (int64_t i = 0; i < n_steps; ++i) HIPCHK(e, hipGraphLaunch(e->graph_exec, e->stream));
-            e->packed_dirty = true;
+            after_update(e);
             e->phase = 0;
             return GPE_OK;
         }
@@ -1314,7 +1337,7 @@ int gpe_residual(gpe_engine* e, gpe_scalars* out, float* d_psi, float* d_resid) 
     if (!e || !out) return GPE_ERR_INVALID;
     if (e->main.n <= 0) FAIL(e, GPE_ERR_STATE, "residual before bind_points");
     int rc;
-    if ((rc = launch_begin(e))) return rc;
+    if ((rc = launch_begin(e, /*force=*/true))) return rc;      // no reverse pass here: the gradient buffer must read zero
     if ((rc = mlp_forward(e, e->main, false))) return rc;
     if ((rc = launch_head_pde(e))) return rc;
     if (e->cfg.w_sym != 0.f) {
@@ -1329,8 +1352,9 @@ int gpe_residual(gpe_engine* e, gpe_scalars* out, float* d_psi, float* d_resid) 
                                   e->main.ld, e->nd.n_out);
     if ((rc = launch_tail(e, false))) return rc;
     hipLaunchKernelGGL(k_update, dim3(1), dim3(1024), 0, e->stream, e->P, e->theta, e->am, e->av, e->grad, e->sums(),
-                       e->lsums(), e->ph, e->oc, e->od, e->hist, e->cap, e->last, bc_count(e), 0, 0);
+                       e->lsums(), e->ph, e->oc, e->od, e->hist, e->cap, e->last, bc_count(e), 0, 0, UPD_TAIL_ARGS);
     HIPCHK(e, hipGetLastError());
+    after_update(e);
     e->phase = 0;
     HIPCHK(e, hipMemcpyAsync(out, e->last, sizeof *out, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));

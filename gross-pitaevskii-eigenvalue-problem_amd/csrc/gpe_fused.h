@@ -1051,12 +1051,12 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_coop(NetDesc nd, const fl
     }
 }
 
-// grad[i] += sum_b gslab[b][i] (+ add[i]).  Block = 64 parameters x 16 slab groups (1024 threads); fixed summation order, so the
+// grad[i] (+)= sum_b gslab[b][i] (+ add[i]).  Block = 64 parameters x 16 slab groups (1024 threads); fixed summation order, so the
 // slab sum is deterministic for a given grid.  The last reduction of a step also adds the boundary-batch gradient `add` and
 // writes the exchange tail (tail_dsc != NULL): grad[P + GT_SUM_R2], grad[P + GT_MSE_SE2].
 __global__ __launch_bounds__(1024) void k_grad_reduce(const float* __restrict__ gslab, int nslab, int Ppad, int P,
                                                        float* __restrict__ grad, const float* __restrict__ add,
-                                                       const double* __restrict__ tail_dsc) {
+                                                       const double* __restrict__ tail_dsc, int assign) {
     __shared__ float red[16][64];
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + lane;
@@ -1070,7 +1070,7 @@ __global__ __launch_bounds__(1024) void k_grad_reduce(const float* __restrict__ 
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += red[k][lane];
         if (add) t += add[i];
-        grad[i] += t;
+        grad[i] = assign ? t : grad[i] + t;        // the first reduction of a step assigns: the gradient needs no zeroing pass
     }
     if (tail_dsc && blockIdx.x == 0 && threadIdx.x == 0) {
         grad[P + GT_SUM_R2] = (float)tail_dsc[0];

@@ -15,5 +15,5 @@ eng.set_params((torch.randn(eng.n_params) * 0.2).numpy())
 eng.bind_points(torch.as_tensor(x, device="cuda"))
 eng.bind_boundary(torch.tensor([[-10.0], [10.0]], device="cuda"))
 eng.run(50); eng.synchronize()
-t0 = time.perf_counter(); eng.run(steps); eng.synchronize(); dt = time.perf_counter() - t0
-print("N=%d: %.1f us/step (%d steps), %.3g points/s" % (N, dt / steps * 1e6, steps, N * steps / dt))
+t0 = time.perf_counter(); eng.run(steps); t_enq = time.perf_counter() - t0; eng.synchronize(); dt = time.perf_counter() - t0
+print("N=%d: %.1f us/step (%d steps), %.3g points/s; host enqueue %.1f us/step" % (N, dt / steps * 1e6, steps, N * steps / dt, t_enq / steps * 1e6))
