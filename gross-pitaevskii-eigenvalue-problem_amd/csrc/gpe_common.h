@@ -66,6 +66,12 @@ struct OptCfg {
     float stop_tol; int stop_patience;
 };
 
+// Point coordinates of a batch: rows [0, na) come from `a`, rows [na, n) from `b` -- the collocation points and, appended
+// behind them, the boundary points (the boundary batch rides in the collocation batch's launches; nothing is copied, both
+// arrays stay the caller's).  b == NULL: a plain batch.
+struct Pts { const float* a; const float* b; long long na; };
+GPE_DEV float pts_at(const Pts& P, long long p, int dim, int k) { return p < P.na ? P.a[p * dim + k] : P.b[(p - P.na) * dim + k]; }
+
 // ------------------------------------------------------------------------------------------------
 // tanh: odd polynomial for |x| < 0.25, 1 - 2/(exp(2|x|)+1) otherwise.  abs error ~1e-7.
 // Shared by both kernel sets so that they agree bit for bit on the activation.

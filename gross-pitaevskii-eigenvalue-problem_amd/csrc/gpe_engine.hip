@@ -170,7 +170,7 @@ __global__ void k_tail(float* __restrict__ grad, const float* __restrict__ add, 
 
 // ------------------------------------------------------------------------------------------------
 struct Batch {
-    const float* x = nullptr;      // [n][dim]
+    Pts pts = {nullptr, nullptr, 0};   // point coordinates [n][dim]: rows [0,na) from a, the rest from b (merged boundary points)
     const float* V = nullptr;
     int64_t n = 0, ld = 0;
     int C = 1, E = 0;              // channels: 1 value + D first derivatives + E second-order channels (gpe_common.h)
@@ -234,6 +234,11 @@ struct gpe_engine {
     const float* orth_host[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [4..6]: precomputed base
     Batch main, bc, sym, aux, mse;
     const float* bc_target = nullptr;
+    // what the caller bound: collocation points / potential, boundary points.  When the boundary batch is small it is MERGED:
+    // appended to the collocation batch (main.pts.b) and handled by the same launches; e->bc stays empty then.
+    const float* ux = nullptr; const float* uV = nullptr; const float* uxb = nullptr;
+    int64_t n_pde = 0, nb_user = 0, nb_merged = 0;
+    bool merge_bc = true;
     const float* mse_target = nullptr;
     int num_cu = 256;
     int phase = 0;                 // 0 idle, 1 after begin, 2 after backward
@@ -260,12 +265,12 @@ static int dev_alloc(gpe_engine* e, Batch* b, T** out, size_t count) {
 
 static int setup_batch(gpe_engine* e, Batch& b, const float* x, int64_t n, int C, int E, bool with_head, const float* V,
                        bool with_store = true) {
-    if (b.n == n && b.C == C && b.E == E && b.O) { b.x = x; b.V = V; return GPE_OK; }
+    if (b.n == n && b.C == C && b.E == E && b.O) { b.pts = Pts{x, nullptr, n}; b.V = V; return GPE_OK; }
     HIPCHK(e, hipStreamSynchronize(e->stream));
     float* keep_xown = nullptr;
     (void)keep_xown;
     free_batch(b);
-    b.x = x; b.V = V; b.n = n; b.C = C; b.E = E;
+    b.pts = Pts{x, nullptr, n}; b.V = V; b.n = n; b.C = C; b.E = E;
     b.ld = round_up(n, 64);
     const int no = e->nd.n_out;
     int rc;
@@ -355,7 +360,7 @@ static bool fwd_coop(gpe_engine* e, const Batch& b) {
 }
 template <int HH, int CC, int EE, int NO>
 static void launch_fcoop_no(gpe_engine* e, Batch& b, unsigned grid, size_t lds, int store) {
-#define CARGS e->nd, e->theta, e->Wpk, b.x, b.stored, b.O, b.n, b.ld, store
+#define CARGS e->nd, e->theta, e->Wpk, b.pts, b.stored, b.O, b.n, b.ld, store
     switch (e->nd.n_lin - 2) {
         case 1: hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, NO, 1>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
         case 2: hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, NO, 2>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
@@ -388,13 +393,13 @@ static void launch_f_forward(gpe_engine* e, Batch& b, unsigned grid, int store) 
         }
     }
     if constexpr (HH > 64) {
-        F_LAUNCH(f_forward, HH, CC, EE, false, grid, 256, fused_fwd_lds(e, false), e->nd, e->theta, e->Wpk, b.x, b.stored, b.O, b.n, b.ld, store);
+        F_LAUNCH(f_forward, HH, CC, EE, false, grid, 256, fused_fwd_lds(e, false), e->nd, e->theta, e->Wpk, b.pts, b.stored, b.O, b.n, b.ld, store);
         return;
     }
     if (e->fwd_wlds && staged_batch(e, b))
-        F_LAUNCH(f_forward, HH, CC, EE, true, grid, 256, fused_fwd_lds(e, true), e->nd, e->theta, e->Wpk, b.x, b.stored, b.O, b.n, b.ld, store);
+        F_LAUNCH(f_forward, HH, CC, EE, true, grid, 256, fused_fwd_lds(e, true), e->nd, e->theta, e->Wpk, b.pts, b.stored, b.O, b.n, b.ld, store);
     else
-        F_LAUNCH(f_forward, HH, CC, EE, false, grid, 256, fused_fwd_lds(e, false), e->nd, e->theta, e->Wpk, b.x, b.stored, b.O, b.n, b.ld, store);
+        F_LAUNCH(f_forward, HH, CC, EE, false, grid, 256, fused_fwd_lds(e, false), e->nd, e->theta, e->Wpk, b.pts, b.stored, b.O, b.n, b.ld, store);
 }
 // reverse-kernel variant for one batch: 3 = cooperative (a workgroup per tile, a wave per 16-feature slice),
 // 2 = weight gradients in registers (1 wave/SIMD),
@@ -418,7 +423,7 @@ static size_t coop_lds(gpe_engine* e, int C) {
 }
 template <int HH, int CC, int EE, int NO>
 static void launch_coop_no(gpe_engine* e, Batch& b, unsigned grid, size_t lds) {
-#define CARGS e->nd, e->theta, e->WpkT, b.x, b.stored, b.Ob, e->gslab, b.n, b.ld, e->Ppad
+#define CARGS e->nd, e->theta, e->WpkT, b.pts, b.stored, b.Ob, e->gslab, b.n, b.ld, e->Ppad
     switch (e->nd.n_lin - 2) {
         case 1: hipLaunchKernelGGL((f_backward_coop<HH, CC, EE, NO, 1>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
         case 2: hipLaunchKernelGGL((f_backward_coop<HH, CC, EE, NO, 2>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
@@ -448,10 +453,10 @@ static void launch_f_backward_coop(gpe_engine* e, Batch& b, unsigned grid, size_
 template <int HH, int CC, int EE>
 static void launch_f_backward(gpe_engine* e, Batch& b, unsigned grid, size_t lds) {
     if constexpr (HH > 64) {
-        B_LAUNCH(HH, CC, EE, false, 0, grid, 256, lds, e->nd, e->theta, e->WpkT, b.x, b.stored, b.Ob, e->gslab, b.n, b.ld, e->Ppad, e->nslab_g);
+        B_LAUNCH(HH, CC, EE, false, 0, grid, 256, lds, e->nd, e->theta, e->WpkT, b.pts, b.stored, b.Ob, e->gslab, b.n, b.ld, e->Ppad, e->nslab_g);
         return;
     } else {
-#define BARGS e->nd, e->theta, e->WpkT, b.x, b.stored, b.Ob, e->gslab, b.n, b.ld, e->Ppad, e->nslab_g
+#define BARGS e->nd, e->theta, e->WpkT, b.pts, b.stored, b.Ob, e->gslab, b.n, b.ld, e->Ppad, e->nslab_g
     const int kind = bwd_kind(e, b);
     if (kind == 3) launch_f_backward_coop<HH, CC, EE>(e, b, grid, lds);
     else if (kind == 2) {
@@ -559,7 +564,7 @@ static int mlp_forward(gpe_engine* e, Batch& b, bool store) {
             const float* Sprev = lin > 0 ? b.S[lin - 1] : nullptr;
             float* Out = (lin == nd.n_lin - 1) ? b.O : b.S[lin];
             dim3 grid(cdiv(b.n, 256), cdiv(nd.width[lin + 1], G_FB));
-            DISPATCH_FWD(b, hipLaunchKernelGGL((g_fwd_layer<CC, EE>), grid, dim3(256), 0, e->stream, nd, lin, e->theta, b.x,
+            DISPATCH_FWD(b, hipLaunchKernelGGL((g_fwd_layer<CC, EE>), grid, dim3(256), 0, e->stream, nd, lin, e->theta, b.pts,
                                                 Sprev, Out, b.n, b.ld));
         }
     }
@@ -628,7 +633,7 @@ static int mlp_backward(gpe_engine* e, Batch& b, bool close = false, bool assign
             const int K = nd.width[lin], Ho = nd.width[lin + 1];
             const float* Sprev = lin > 0 ? b.S[lin - 1] : nullptr;
             dim3 gw(Ho, cdiv(K, G_KB));
-            DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_weight<CC, EE>), gw, dim3(256), 0, e->stream, nd, lin, b.x, Sprev, Zb,
+            DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_weight<CC, EE>), gw, dim3(256), 0, e->stream, nd, lin, b.pts, Sprev, Zb,
                                                 e->grad, b.n, b.ld));
             if (lin > 0) {
                 dim3 gd(cdiv(b.n, 256), cdiv(K, G_FB));
@@ -664,7 +669,7 @@ static void fill_phys(gpe_engine* e) {
     p.perturb_scale = c.perturb_scale; p.bc_nn_scale = c.bc_nn_scale;
     p.w_pde = c.w_pde; p.w_bc = c.w_bc; p.w_norm = c.w_norm; p.w_sym = c.w_sym; p.w_orth = c.w_orth;
     p.sym_sign = c.sym_sign; p.dx = c.dx; p.w_riesz = c.w_riesz;
-    p.n_global = (double)(c.n_global > 0 ? c.n_global : (e->main.n > 0 ? e->main.n : 1));
+    p.n_global = (double)(c.n_global > 0 ? c.n_global : (e->n_pde > 0 ? e->n_pde : 1));
     p.inv_world = 1.0f / (float)(c.world_size > 0 ? c.world_size : 1);
     int no = 0;
     for (int j = 0; j < GPE_MAX_ORTH; ++j) if (e->orth_host[j]) no = j + 1;      // [4..6] are the precomputed base
@@ -847,6 +852,8 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
     if (ok) {
         ok = alloc((void**)&e->grad_bc, (size_t)e->P * 4);
         if (ok && e->path == GPE_PATH_FUSED) ok = alloc((void**)&e->gslab_bc, (size_t)e->nslab * e->Ppad * 4);
+        const char* envb = getenv("GPE_MERGE_BC");
+        e->merge_bc = !envb || atoi(envb) != 0;
         const char* envg = getenv("GPE_GRAPH");
         e->use_graph = envg && atoi(envg) != 0;    // opt-in: measured 6 % slower than plain launches on ROCm 7.2 (141 vs 133 us/step)
         const char* envq = getenv("GPE_SIDE_STREAM");
@@ -945,11 +952,27 @@ int gpe_reset_optimizer(gpe_engine* e, float lr) {
     return reset_opt(e, lr);
 }
 
+// (re)build the collocation batch from what is bound; decides whether the boundary points ride in it
+static int rebuild_main(gpe_engine* e) {
+    if (!e->ux) return GPE_OK;
+    const bool merged = e->merge_bc && e->uxb && e->nb_user > 0 && e->nb_user * 8 <= e->n_pde;
+    const int64_t n_tot = e->n_pde + (merged ? e->nb_user : 0);
+    int rc = setup_batch(e, e->main, e->ux, n_tot, e->nd.dim + 2, 1, true, e->uV);     // value, dim first derivatives, Laplacian
+    if (rc) return rc;
+    e->main.pts = Pts{e->ux, merged ? e->uxb : nullptr, e->n_pde};
+    e->nb_merged = merged ? e->nb_user : 0;
+    if (merged) free_batch(e->bc);
+    else if (e->uxb && e->nb_user > 0) { if ((rc = setup_batch(e, e->bc, e->uxb, e->nb_user, 1, 0, false, nullptr))) return rc; }
+    else free_batch(e->bc);
+    return GPE_OK;
+}
+
 int gpe_bind_points(gpe_engine* e, const float* d_x, int64_t n_local, const float* d_V) {
     if (!e) return GPE_ERR_INVALID;
     if (!d_x || n_local <= 0) FAIL(e, GPE_ERR_INVALID, "bind_points: need n_local > 0 points");
     if (e->cfg.potential == GPE_POT_PRECOMPUTED && !d_V) FAIL(e, GPE_ERR_INVALID, "precomputed potential requested but d_V is NULL");
-    int rc = setup_batch(e, e->main, d_x, n_local, e->nd.dim + 2, 1, true, d_V);     // value, dim first derivatives, Laplacian
+    e->ux = d_x; e->uV = d_V; e->n_pde = n_local;
+    int rc = rebuild_main(e);
     if (rc) return rc;
     if (e->cfg.w_sym != 0.f) {
         // symmetry batch: [x ; -x], value only
@@ -967,16 +990,23 @@ int gpe_bind_points(gpe_engine* e, const float* d_x, int64_t n_local, const floa
         HIPCHK(e, hipGetLastError());
     }
     fill_phys(e);
+    e->acc_clean = false;
     HIPCHK(e, hipStreamSynchronize(e->stream));
     return GPE_OK;
 }
 
 int gpe_bind_boundary(gpe_engine* e, const float* d_xb, int64_t n_b, const float* d_target) {
     if (!e) return GPE_ERR_INVALID;
-    if (!d_xb || n_b <= 0) { free_batch(e->bc); e->bc_target = nullptr; return GPE_OK; }
-    e->bc_target = d_target;
-    int rc = setup_batch(e, e->bc, d_xb, n_b, 1, 0, false, nullptr);
-    if (rc) return rc;
+    if (!d_xb || n_b <= 0) { e->uxb = nullptr; e->nb_user = 0; e->bc_target = nullptr; }
+    else { e->uxb = d_xb; e->nb_user = n_b; e->bc_target = d_target; }
+    if (e->ux) {
+        int rc = rebuild_main(e);
+        if (rc) return rc;
+    } else if (e->uxb) {             // points not bound yet: keep a plain boundary batch until they are
+        int rc = setup_batch(e, e->bc, e->uxb, e->nb_user, 1, 0, false, nullptr);
+        if (rc) return rc;
+    } else free_batch(e->bc);
+    e->acc_clean = false;
     HIPCHK(e, hipStreamSynchronize(e->stream));
     return GPE_OK;
 }
@@ -1050,17 +1080,18 @@ static unsigned head_grid(gpe_engine* e, int64_t n) { return (unsigned)std::min<
 static int launch_head_pde(gpe_engine* e) {
     Batch& b = e->main;
     dim3 g(head_grid(e, b.n));
-    DISPATCH_TRAIN(b, hipLaunchKernelGGL((k_head_pde<CC, EE>), g, dim3(256), 0, e->stream, e->ph, e->base_norm, b.x, b.V, b.O,
-                                        (const float* const*)e->orth_dev, b.u, b.Hu, b.ux, e->sums(), b.n, b.ld));
+    DISPATCH_TRAIN(b, hipLaunchKernelGGL((k_head_pde<CC, EE>), g, dim3(256), 0, e->stream, e->ph, e->base_norm, b.pts, b.V, b.O,
+                                        (const float* const*)e->orth_dev, b.u, b.Hu, b.ux, e->sums(), b.n, b.ld, e->n_pde,
+                                        e->bc_target, b.Ob, e->lsums()));
     HIPCHK(e, hipGetLastError());
     return GPE_OK;
 }
 static int launch_seed_pde(gpe_engine* e, float* d_resid, int want_seeds) {
     Batch& b = e->main;
-    dim3 g(head_grid(e, b.n));
-    DISPATCH_TRAIN(b, hipLaunchKernelGGL((k_seed_pde<CC, EE>), g, dim3(256), 0, e->stream, e->ph, b.x, b.V,
+    dim3 g(head_grid(e, e->n_pde));
+    DISPATCH_TRAIN(b, hipLaunchKernelGGL((k_seed_pde<CC, EE>), g, dim3(256), 0, e->stream, e->ph, b.pts, b.V,
                                         (const float* const*)e->orth_dev, b.u, b.Hu, b.ux, e->sums(), b.Ob, d_resid, e->dsc(),
-                                        b.n, b.ld, want_seeds));
+                                        e->n_pde, b.ld, want_seeds));      // collocation rows only; boundary rows were seeded by the head kernel
     HIPCHK(e, hipGetLastError());
     return GPE_OK;
 }
@@ -1079,8 +1110,8 @@ int gpe_step_begin(gpe_engine* e) {
     if ((rc = launch_head_pde(e))) return rc;
     if (e->cfg.w_sym != 0.f) {
         if ((rc = mlp_forward(e, e->sym, true))) return rc;
-        hipLaunchKernelGGL(k_head_sym, dim3(cdiv(e->main.n, 256)), dim3(256), 0, e->stream, e->ph, e->sym.O, e->sums(),
-                           e->main.n, e->sym.ld);
+        hipLaunchKernelGGL(k_head_sym, dim3(cdiv(e->n_pde, 256)), dim3(256), 0, e->stream, e->ph, e->sym.O, e->sums(),
+                           e->n_pde, e->sym.ld);
         HIPCHK(e, hipGetLastError());
     }
     e->phase = 1;
@@ -1107,7 +1138,7 @@ static int bc_fork(gpe_engine* e, bool with_backward) {
     auto body = [&]() -> int {
         int r;
         if ((r = mlp_forward(e, e->bc, true))) return r;
-        hipLaunchKernelGGL(k_head_seed_bc, dim3(cdiv(e->bc.n, 256)), dim3(256), 0, e->stream, e->ph, e->base_norm, e->bc.x,
+        hipLaunchKernelGGL(k_head_seed_bc, dim3(cdiv(e->bc.n, 256)), dim3(256), 0, e->stream, e->ph, e->base_norm, e->bc.pts.a,
                            e->bc_target, e->bc.O, e->bc.Ob, e->lsums(), e->bc.n, e->bc.ld);
         HIPCHK(e, hipGetLastError());
         if (with_backward && (r = mlp_backward(e, e->bc))) return r;
@@ -1140,8 +1171,8 @@ int gpe_step_backward(gpe_engine* e) {
     const bool with_sym = e->cfg.w_sym != 0.f;
     if ((rc = mlp_backward(e, e->main, /*close=*/!with_sym))) return rc;
     if (with_sym) {
-        hipLaunchKernelGGL(k_seed_sym, dim3(cdiv(e->main.n, 256)), dim3(256), 0, e->stream, e->ph, e->sym.O, e->sym.Ob,
-                           e->main.n, e->sym.ld);
+        hipLaunchKernelGGL(k_seed_sym, dim3(cdiv(e->n_pde, 256)), dim3(256), 0, e->stream, e->ph, e->sym.O, e->sym.Ob,
+                           e->n_pde, e->sym.ld);
         HIPCHK(e, hipGetLastError());
         if ((rc = mlp_backward(e, e->sym, /*close=*/true, /*assign=*/false))) return rc;
     }
@@ -1156,7 +1187,10 @@ static void after_update(gpe_engine* e) {          // host-side mirror of what k
     e->acc_clean = true;
     e->packed_dirty = false;
 }
-static double bc_count(gpe_engine* e) { return (e->bc.n > 0 && e->cfg.w_bc != 0.f) ? (double)e->bc.n * e->nd.n_out : 0.0; }
+static double bc_count(gpe_engine* e) {
+    const int64_t nb = e->nb_merged > 0 ? e->nb_merged : e->bc.n;
+    return (nb > 0 && e->cfg.w_bc != 0.f) ? (double)nb * e->nd.n_out : 0.0;
+}
 
 int gpe_step_update(gpe_engine* e) {
     if (!e) return GPE_ERR_INVALID;
@@ -1175,17 +1209,17 @@ int gpe_bind_target(gpe_engine* e, const float* d_target) {
     if (e->main.n <= 0) FAIL(e, GPE_ERR_STATE, "bind_target before bind_points");
     e->mse_target = d_target;
     if (!d_target) { free_batch(e->mse); return GPE_OK; }
-    return setup_batch(e, e->mse, e->main.x, e->main.n, 1, 0, false, nullptr);
+    return setup_batch(e, e->mse, e->ux, e->n_pde, 1, 0, false, nullptr);
 }
 
 int gpe_mse_begin(gpe_engine* e) {
     if (!e) return GPE_ERR_INVALID;
     if (!e->mse_target || e->mse.n <= 0) FAIL(e, GPE_ERR_STATE, "mse step before bind_target");
     int rc;
-    e->mse.x = e->main.x;
+    e->mse.pts = Pts{e->ux, nullptr, e->n_pde};
     if ((rc = launch_begin(e))) return rc;
     if ((rc = mlp_forward(e, e->mse, true))) return rc;
-    hipLaunchKernelGGL(k_seed_mse, dim3(head_grid(e, e->mse.n)), dim3(256), 0, e->stream, e->ph, e->mse.x, e->mse_target,
+    hipLaunchKernelGGL(k_seed_mse, dim3(head_grid(e, e->mse.n)), dim3(256), 0, e->stream, e->ph, e->mse.pts.a, e->mse_target,
                        e->mse.O, e->mse.Ob, e->dsc() + 2, e->mse.n, e->mse.ld);
     HIPCHK(e, hipGetLastError());
     if ((rc = mlp_backward(e, e->mse, /*close=*/true))) return rc;
@@ -1272,7 +1306,8 @@ static std::vector<char> graph_key_of(gpe_engine* e) {
     auto put = [&](const void* p, size_t n) { const char* c = (const char*)p; k.insert(k.end(), c, c + n); };
     put(&e->ph, sizeof e->ph); put(&e->oc, sizeof e->oc); put(&e->base_norm, sizeof e->base_norm);
     for (Batch* b : {&e->main, &e->bc, &e->sym}) {
-        const void* ptrs[] = {b->x, b->V, b->O, b->Ob, b->u, b->Hu, b->ux, b->stored, b->A0, b->A1};
+        const void* ptrs[] = {b->pts.a, b->pts.b, b->V, b->O, b->Ob, b->u, b->Hu, b->ux, b->stored, b->A0, b->A1};
+        put(&b->pts.na, sizeof b->pts.na);
         put(ptrs, sizeof ptrs); put(&b->n, sizeof b->n); put(&b->C, sizeof b->C);
     }
     const void* more[] = {e->bc_target, e->grad, e->dbl, e->stream};
@@ -1342,13 +1377,13 @@ int gpe_residual(gpe_engine* e, gpe_scalars* out, float* d_psi, float* d_resid) 
     if ((rc = launch_head_pde(e))) return rc;
     if (e->cfg.w_sym != 0.f) {
         if ((rc = mlp_forward(e, e->sym, false))) return rc;
-        hipLaunchKernelGGL(k_head_sym, dim3(cdiv(e->main.n, 256)), dim3(256), 0, e->stream, e->ph, e->sym.O, e->sums(),
-                           e->main.n, e->sym.ld);
+        hipLaunchKernelGGL(k_head_sym, dim3(cdiv(e->n_pde, 256)), dim3(256), 0, e->stream, e->ph, e->sym.O, e->sums(),
+                           e->n_pde, e->sym.ld);
     }
     if ((rc = launch_seed_pde(e, d_resid, 0))) return rc;
     if ((rc = bc_fork(e, false))) return rc;
     if ((rc = bc_join(e))) return rc;
-    if (d_psi) hipLaunchKernelGGL(k_copy_psi, dim3(cdiv(e->main.n, 256)), dim3(256), 0, e->stream, e->main.u, d_psi, e->main.n,
+    if (d_psi) hipLaunchKernelGGL(k_copy_psi, dim3(cdiv(e->n_pde, 256)), dim3(256), 0, e->stream, e->main.u, d_psi, e->n_pde,
                                   e->main.ld, e->nd.n_out);
     if ((rc = launch_tail(e, false))) return rc;
     hipLaunchKernelGGL(k_update, dim3(1), dim3(1024), 0, e->stream, e->P, e->theta, e->am, e->av, e->grad, e->sums(),

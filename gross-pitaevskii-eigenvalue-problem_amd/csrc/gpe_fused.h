@@ -192,7 +192,7 @@ GPE_DEV void layer0_st(const float* w0s, const float (&xv)[3], int nt, int q, f3
 template <int H, int C, int E, int NOUT, bool WLDS>
 __global__ __launch_bounds__(256, ((C <= 5 && H <= 64) ? GPE_FWD_WAVES : 1)) void f_forward(NetDesc nd, const float* __restrict__ theta,
                                                                  const float* __restrict__ Wpk,
-                                                                 const float* __restrict__ x, float* __restrict__ stored,
+                                                                 Pts x, float* __restrict__ stored,
                                                                  float* __restrict__ O, int64_t N, int64_t ld,
                                                                  int store_acts) {
     constexpr int D = C - 1 - E, NT = H / 16, NF = NT * 4;
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256, ((C <= 5 && H <= 64) ? GPE_FWD_WAVES : 1)) voi
     if (wave0 < ntiles) {
         const int64_t p0 = min(wave0 * 16 + m, N - 1);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) if (k < dim) xn[k] = x[p0 * dim + k];
+        for (int k = 0; k < 3; ++k) if (k < dim) xn[k] = pts_at(x, p0, dim, k);
     }
     for (int64_t tile = wave0; tile < ntiles; tile += nwaves) {
         const int64_t pm = tile * 16 + m;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, ((C <= 5 && H <= 64) ? GPE_FWD_WAVES : 1)) voi
         if (tile + nwaves < ntiles) {
             const int64_t pn = min((tile + nwaves) * 16 + m, N - 1);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) if (k < dim) xn[k] = x[pn * dim + k];
+            for (int k = 0; k < 3; ++k) if (k < dim) xn[k] = pts_at(x, pn, dim, k);
         }
 
         float bufA[C][NF], bufB[C][NF];
@@ -354,7 +354,7 @@ GPE_DEV unsigned long long stamp_now() {
 template <int H, int C, int E, int NOUT, bool WLDS, int NHH>
 __global__ __launch_bounds__((NHH > 0 ? 256 : (WLDS ? 512 : 256)), ((NHH > 0 || H > 64) ? 1 : (C <= 5 ? GPE_BWD_WAVES : 1))) void f_backward(NetDesc nd, const float* __restrict__ theta,
                                                                   const float* __restrict__ WpkT,
-                                                                  const float* __restrict__ x,
+                                                                  Pts x,
                                                                   const float* __restrict__ stored,
                                                                   const float* __restrict__ Ob, float* __restrict__ gslab,
                                                                   int64_t N, int64_t ld, int Ppad, int nslab) {
@@ -409,7 +409,7 @@ __global__ __launch_bounds__((NHH > 0 ? 256 : (WLDS ? 512 : 256)), ((NHH > 0 || 
         const int64_t pl = valid ? pm : N - 1;
         float xv[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < 3; ++k) if (k < dim) xv[k] = x[pl * dim + k];
+        for (int k = 0; k < 3; ++k) if (k < dim) xv[k] = pts_at(x, pl, dim, k);
         float ob[NOUT][C];
 #pragma unroll
         for (int o = 0; o < NOUT; ++o)
@@ -665,7 +665,7 @@ __global__ __launch_bounds__((NHH > 0 ? 256 : (WLDS ? 512 : 256)), ((NHH > 0 || 
 // A tile's latency is ~NT times shorter than in f_forward: the kernel of choice when a batch has only a few tiles per wave.
 template <int H, int C, int E, int NOUT, int NHH>
 __global__ __launch_bounds__(H * 4, 2) void f_forward_coop(NetDesc nd, const float* __restrict__ theta,
-                                                           const float* __restrict__ Wpk, const float* __restrict__ x,
+                                                           const float* __restrict__ Wpk, Pts x,
                                                            float* __restrict__ stored, float* __restrict__ O, int64_t N,
                                                            int64_t ld, int store_acts) {
     constexpr int D = C - 1 - E, NT = H / 16, NTHR = 64 * NT;
@@ -695,7 +695,7 @@ __global__ __launch_bounds__(H * 4, 2) void f_forward_coop(NetDesc nd, const flo
         const int64_t pl = valid ? pm : N - 1;
         float xv[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < 3; ++k) if (k < dim) xv[k] = x[pl * dim + k];
+        for (int k = 0; k < 3; ++k) if (k < dim) xv[k] = pts_at(x, pl, dim, k);
         f32x4 a[C];
         {   // layer 0, own slice
             f32x4 st[C];
@@ -810,7 +810,7 @@ GPE_DEV void row_reduce4_add(const float (&v)[4], float* dst16, int m, int q) {
 
 template <int H, int C, int E, int NOUT, int NHH>
 __global__ __launch_bounds__(H * 4, 2) void f_backward_coop(NetDesc nd, const float* __restrict__ theta,
-                                                            const float* __restrict__ WpkT, const float* __restrict__ x,
+                                                            const float* __restrict__ WpkT, Pts x,
                                                             const float* __restrict__ stored, const float* __restrict__ Ob,
                                                             float* __restrict__ gslab, int64_t N, int64_t ld, int Ppad) {
     constexpr int D = C - 1 - E, NT = H / 16, NTHR = 64 * NT;
@@ -864,7 +864,7 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_coop(NetDesc nd, const fl
         const int64_t pl = valid ? pm : N - 1;
         float xv[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < 3; ++k) if (k < dim) xv[k] = x[pl * dim + k];
+        for (int k = 0; k < 3; ++k) if (k < dim) xv[k] = pts_at(x, pl, dim, k);
         float ob[NOUT][C];
 #pragma unroll
         for (int o = 0; o < NOUT; ++o)

@@ -16,7 +16,7 @@
 // layer lin, or the output jets O when lin == n_lin-1.
 template <int C, int E>
 __global__ __launch_bounds__(256) void g_fwd_layer(NetDesc nd, int lin, const float* __restrict__ theta,
-                                                   const float* __restrict__ x, const float* __restrict__ Sprev,
+                                                   Pts x, const float* __restrict__ Sprev,
                                                    float* __restrict__ Out, int64_t N, int64_t ld) {
     constexpr int D = C - 1 - E;
     int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void g_fwd_layer(NetDesc nd, int lin, const fl
     }
     if (lin == 0) {
         for (int k = 0; k < K; ++k) {
-            float xk = x[m * K + k];
+            float xk = pts_at(x, m, K, k);
 #pragma unroll
             for (int f = 0; f < G_FB; ++f) {
                 int n = min(n0 + f, Ho - 1);
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void g_bwd_data(NetDesc nd, int lin, const flo
 // One block per (n, 16-wide k block); the block walks all points -> deterministic, no atomics.
 #define G_KB 16
 template <int C, int E>
-__global__ __launch_bounds__(256) void g_bwd_weight(NetDesc nd, int lin, const float* __restrict__ x,
+__global__ __launch_bounds__(256) void g_bwd_weight(NetDesc nd, int lin, Pts x,
                                                     const float* __restrict__ Sprev, const float* __restrict__ Zb,
                                                     float* __restrict__ grad, int64_t N, int64_t ld) {
     constexpr int D = C - 1 - E;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void g_bwd_weight(NetDesc nd, int lin, const f
             int k = k0 + i;
             if (k >= K) break;
             if (lin == 0) {
-                float v = z[0] * x[m * K + k];
+                float v = z[0] * pts_at(x, m, K, k);
                 if (C > 1) {
 #pragma unroll
                     for (int j = 0; j < D; ++j) if (j == k) v += z[1 + j];

@@ -34,19 +34,44 @@ GPE_DEV void load_u_jets(const Phys& ph, const float* __restrict__ O, int64_t ld
 
 // ---- phase 1: u, Hu per point; block partial sums into sums[] (double atomics) ---------------------
 template <int C, int E>
-__global__ __launch_bounds__(256) void k_head_pde(Phys ph, float base_norm, const float* __restrict__ x,
+// Rows [n_pde, N) of a merged batch are boundary points (refine/harmonic_pinn_simulation.py:198-210): for those the kernel
+// forms e = base + s*NN - target, adds e^2 to lsums[LS_BC_SE2] and writes their seeds Ob = w_bc*2/cnt * e * s / world directly
+// (they do not depend on mu) -- what k_head_seed_bc does for a separate boundary batch.
+__global__ __launch_bounds__(256) void k_head_pde(Phys ph, float base_norm, Pts x,
                                                   const float* __restrict__ Vpre, const float* __restrict__ O,
                                                   const float* const* __restrict__ orth, float* __restrict__ u_out,
                                                   float* __restrict__ Hu_out, float* __restrict__ ux_out,
-                                                  double* __restrict__ sums, int64_t N, int64_t ld) {
+                                                  double* __restrict__ sums, int64_t N, int64_t ld, int64_t n_pde,
+                                                  const float* __restrict__ bc_target, float* __restrict__ Ob,
+                                                  double* __restrict__ lsums) {
     constexpr int D = C - 1 - E;
     __shared__ double red[4];
     double num = 0.0, den = 0.0, so[GPE_MAX_ORTH] = {0.0, 0.0, 0.0, 0.0};
-    double rzk = 0.0, rzp = 0.0, rzi = 0.0;
+    double rzk = 0.0, rzp = 0.0, rzi = 0.0, bse = 0.0;
     // grid-stride: few workgroups, one double atomic each per sum (same-address atomics serialise at ~25 ns apiece)
     for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < N; m += (int64_t)gridDim.x * 256) {
         float xv[3] = {0.f, 0.f, 0.f};
-        for (int k = 0; k < ph.dim; ++k) xv[k] = x[m * ph.dim + k];
+        for (int k = 0; k < ph.dim; ++k) xv[k] = pts_at(x, m, ph.dim, k);
+        if (m >= n_pde) {                              // boundary point riding in this batch
+            const int64_t mb = m - n_pde;
+            const float cnt = (float)((N - n_pde) * ph.n_out);
+            float fenv = 1.0f;
+            if (ph.envelope == GPE_ENV_SIN) { float f1, f2; envelope_at(ph, xv[0], fenv, f1, f2); }
+            for (int o = 0; o < ph.n_out; ++o) {
+                float e = ph.bc_nn_scale * fenv * O[(int64_t)o * ld + m];
+                if (ph.base_mode >= 0 && o == 0 && ph.base_kind != GPE_BASE_PRECOMPUTED) {
+                    float phi, p1, p2;
+                    base_at(ph, xv[0], base_norm, phi, p1, p2);
+                    e += phi;
+                }
+                if (bc_target) e -= bc_target[mb * ph.n_out + o];
+                bse += (double)(e * e);
+                Ob[(int64_t)o * ld + m] = ph.w_bc * 2.0f / cnt * e * ph.bc_nn_scale * fenv * ph.inv_world;
+#pragma unroll
+                for (int c = 1; c < C; ++c) Ob[((int64_t)c * ph.n_out + o) * ld + m] = 0.f;
+            }
+            continue;
+        }
         float V = potential_at(ph, xv, Vpre, m);
         float U[2][C];
         for (int o = 0; o < ph.n_out; ++o) load_u_jets<C, E>(ph, O, ld, m, o, xv, base_norm, orth, U[o]);
@@ -96,6 +121,10 @@ __global__ __launch_bounds__(256) void k_head_pde(Phys ph, float base_norm, cons
         t = block_sum_256(rzp, red); if (threadIdx.x == 0) atomicAdd(&sums[S_RZ_P], t);
         t = block_sum_256(rzi, red); if (threadIdx.x == 0) atomicAdd(&sums[S_RZ_I], t);
     }
+    if (n_pde < N) {
+        double t = block_sum_256(bse, red);
+        if (threadIdx.x == 0 && t != 0.0) atomicAdd(&lsums[LS_BC_SE2], t);
+    }
     double r = block_sum_256(num, red);
     if (threadIdx.x == 0) atomicAdd(&sums[S_NUM], r);
     r = block_sum_256(den, red);
@@ -109,7 +138,7 @@ __global__ __launch_bounds__(256) void k_head_pde(Phys ph, float base_norm, cons
 // ---- phase 2: residual + seeds -------------------------------------------------------------------
 // lambda = num/den (global sums), r = Hu - lambda u, sum r^2 -> gtail[GT_SUM_R2]; Ob = dLoss/dO.
 template <int C, int E>
-__global__ __launch_bounds__(256) void k_seed_pde(Phys ph, const float* __restrict__ x, const float* __restrict__ Vpre,
+__global__ __launch_bounds__(256) void k_seed_pde(Phys ph, Pts x, const float* __restrict__ Vpre,
                                                   const float* const* __restrict__ orth,
                                                   const float* __restrict__ u_in, const float* __restrict__ Hu_in,
                                                   const float* __restrict__ ux_in,
@@ -123,7 +152,7 @@ __global__ __launch_bounds__(256) void k_seed_pde(Phys ph, const float* __restri
         float lam = (float)(sums[S_NUM] / sums[S_DEN]);
         float I = (float)sums[S_DEN] * ph.dx;
         float xv[3] = {0.f, 0.f, 0.f};
-        for (int k = 0; k < ph.dim; ++k) xv[k] = x[m * ph.dim + k];
+        for (int k = 0; k < ph.dim; ++k) xv[k] = pts_at(x, m, ph.dim, k);
         float V = potential_at(ph, xv, Vpre, m);
         float u[2] = {0.f, 0.f}, r[2] = {0.f, 0.f}, rb[2] = {0.f, 0.f};
         float cr = (float)(2.0 * (double)ph.w_pde / ph.n_global);

@@ -497,14 +497,18 @@ def _trajectory(env, kw, N, steps, use_run):
                                         dx=12 / 499), 500),
                                   (dict(layers=[2, 64, 64, 64, 64, 1], gamma=50.0, dx=0.01), 777)])
 def test_side_stream_and_graph_replay_change_nothing(kw, N):
-    """Boundary batch on the side stream (default) vs in line (GPE_SIDE_STREAM=0) vs hipGraph replay of gpe_run (GPE_GRAPH=1):
+    """Boundary batch merged into the collocation batch (default when it is small) vs separate on the side stream vs separate in
+    line (GPE_SIDE_STREAM=0), each with and without hipGraph replay of gpe_run (GPE_GRAPH=1):
     same kernels and arithmetic; the fused kernels accumulate weight gradients with LDS float atomics from several waves, so
     two runs agree to fp32 round-off, not bit for bit (the trajectories stay within 1e-5 over 12 steps)."""
     def same(a, b):
         return np.abs(np.asarray(a) - np.asarray(b)).max() <= 1e-5 * max(1.0, np.abs(np.asarray(b)).max())
-    base_l, base_t, _ = _trajectory({"GPE_SIDE_STREAM": "0", "GPE_GRAPH": "0"}, kw, N, 12, use_run=True)
-    for env in ({"GPE_SIDE_STREAM": "1", "GPE_GRAPH": "0"}, {"GPE_SIDE_STREAM": "1", "GPE_GRAPH": "1"},
-                {"GPE_SIDE_STREAM": "0", "GPE_GRAPH": "1"}):
+    base_l, base_t, _ = _trajectory({"GPE_MERGE_BC": "0", "GPE_SIDE_STREAM": "0", "GPE_GRAPH": "0"}, kw, N, 12, use_run=True)
+    for env in ({"GPE_MERGE_BC": "0", "GPE_SIDE_STREAM": "1", "GPE_GRAPH": "0"},
+                {"GPE_MERGE_BC": "0", "GPE_SIDE_STREAM": "1", "GPE_GRAPH": "1"},
+                {"GPE_MERGE_BC": "0", "GPE_SIDE_STREAM": "0", "GPE_GRAPH": "1"},
+                {"GPE_MERGE_BC": "1", "GPE_GRAPH": "0"},          # boundary points appended to the collocation batch (default)
+                {"GPE_MERGE_BC": "1", "GPE_GRAPH": "1"}):
         l, t, _ = _trajectory(env, kw, N, 12, use_run=True)
         assert same(l, base_l), env
         assert same(t, base_t), env
