@@ -203,16 +203,16 @@ def main():
         ach = 2.0 * f_fwd * n_local / bwd_s / 1e12 if bwd_s > 0 else 0.0
         ach_f = f_fwd * n_local / fwd_s / 1e12 if fwd_s > 0 else 0.0
         # HBM bytes per launch of the dominant kernel from the committed PMC run of this same workload
-        # (profiles/r01/traffic_ns_v6.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 1/2-fetch correction applied)
+        # (profiles/r01/traffic_ns_v7.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 1/2-fetch correction applied)
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01", "traffic_ns_v6.json")
+        tpath = os.path.join(ROOT, "profiles", "r01", "traffic_ns_v7.json")
         if args.workload == "ns_2d_4x64" and os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 for k, v in tj["kernels"].items():          # the collocation batch's launch is the largest f_backward* entry
                     if "f_backward" in k and (traffic is None or v["hbm_bytes_per_point"] * n_local > traffic):
                         traffic = v["hbm_bytes_per_point"] * n_local
-                        traffic_src = "profiles/r01/traffic_ns_v6.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                        traffic_src = "profiles/r01/traffic_ns_v7.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
             except Exception:
                 pass
         out = {
