@@ -56,6 +56,7 @@ struct OptDev {
     int es_count;         // steps since the best loss
     double es_best;
     long long stop_step;
+    double b1p, b2p;      // beta1^step, beta2^step (running products: the Adam bias corrections without a pow() per step)
 };
 
 struct OptCfg {

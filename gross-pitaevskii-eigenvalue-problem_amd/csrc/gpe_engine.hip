@@ -59,7 +59,9 @@ __global__ __launch_bounds__(1024) void k_update(int P, float* __restrict__ thet
                                                   double* __restrict__ dbl, int n_dbl) {
     __shared__ double red[16];
     __shared__ float s_coef, s_ss, s_b2s;
-    __shared__ int s_skip;
+    __shared__ int s_skip, s_book, s_frozen;
+    __shared__ long long s_step;
+    __shared__ gpe_scalars s_rec;
     double acc = 0.0;
     for (int i = threadIdx.x; i < P; i += 1024) { double g = grad[i]; acc += g * g; }
 #pragma unroll
@@ -92,8 +94,11 @@ __global__ __launch_bounds__(1024) void k_update(int P, float* __restrict__ thet
         double lr = od->lr;
         float coef = 1.0f;
         if (oc.clip_norm > 0.f && !mse_mode) coef = (float)fmin(1.0, (double)oc.clip_norm / (gn + 1e-6));
-        double bc1 = 1.0 - pow((double)oc.beta1, (double)step);
-        double bc2 = 1.0 - pow((double)oc.beta2, (double)step);
+        const bool commit = do_update && !skip && !frozen;
+        const double b1p = commit ? od->b1p * (double)oc.beta1 : od->b1p, b2p = commit ? od->b2p * (double)oc.beta2 : od->b2p;
+        if (commit) { od->b1p = b1p; od->b2p = b2p; }
+        double bc1 = 1.0 - b1p;
+        double bc2 = 1.0 - b2p;
         s_coef = coef;
         s_ss = (float)(lr / bc1);
         s_b2s = (float)sqrt(bc2);
@@ -102,6 +107,16 @@ __global__ __launch_bounds__(1024) void k_update(int P, float* __restrict__ thet
         r.loss = loss; r.pde = pde; r.bc = bc; r.norm = nrm; r.sym = sym; r.orth = orth; r.mu = lam;
         r.num = num; r.den = den; r.sum_r2 = sr2; r.integral = I; r.grad_norm = gn; r.lr = lr;
         r.step = (double)step; r.nonfinite = skip ? 1.0 : 0.0; r.riesz = riesz;
+        s_rec = r; s_step = step; s_frozen = frozen; s_book = 1;
+    }
+    __syncthreads();
+    // bookkeeping (record, history, early stop, scheduler: double-precision log / pow / cos) on the last thread, concurrently
+    // with the Adam loop of the others
+    if (threadIdx.x == 1023 && s_book) {
+        const gpe_scalars r = s_rec;
+        const long long step = s_step;
+        const int frozen = s_frozen, skip = r.nonfinite != 0.0;
+        const double loss = r.loss;
         if (!frozen) *last = r;
         if (do_update && !frozen) {
             if (!skip) {
@@ -140,7 +155,6 @@ __global__ __launch_bounds__(1024) void k_update(int P, float* __restrict__ thet
             }
         }
     }
-    __syncthreads();
     if (!s_skip) {
         const float coef = s_coef, ss = s_ss, b2s = s_b2s;
         const float b1 = oc.beta1, b2 = oc.beta2, eps = oc.eps;
@@ -690,7 +704,7 @@ static int reset_opt(gpe_engine* e, float lr) {
     OptDev h;
     memset(&h, 0, sizeof h);
     h.lr = lr; h.lr0 = lr; h.best = INFINITY; h.num_bad = 0; h.nonfinite = 0; h.step = 0;
-    h.stopped = 0; h.es_count = 0; h.es_best = INFINITY; h.stop_step = 0;
+    h.stopped = 0; h.es_count = 0; h.es_best = INFINITY; h.stop_step = 0; h.b1p = 1.0; h.b2p = 1.0;
     HIPCHK(e, hipMemcpyAsync(e->od, &h, sizeof h, hipMemcpyHostToDevice, e->stream));
     HIPCHK(e, hipMemsetAsync(e->am, 0, (size_t)e->P * sizeof(float), e->stream));
     HIPCHK(e, hipMemsetAsync(e->av, 0, (size_t)e->P * sizeof(float), e->stream));
@@ -940,6 +954,7 @@ int gpe_set_adam_state(gpe_engine* e, const float* hm, const float* hv, size_t n
     HIPCHK(e, hipMemcpyAsync(&h, e->od, sizeof h, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     h.step = step;
+    h.b1p = pow((double)e->oc.beta1, (double)step); h.b2p = pow((double)e->oc.beta2, (double)step);
     HIPCHK(e, hipMemcpyAsync(e->am, hm, n * 4, hipMemcpyHostToDevice, e->stream));
     HIPCHK(e, hipMemcpyAsync(e->av, hv, n * 4, hipMemcpyHostToDevice, e->stream));
     HIPCHK(e, hipMemcpyAsync(e->od, &h, sizeof h, hipMemcpyHostToDevice, e->stream));
