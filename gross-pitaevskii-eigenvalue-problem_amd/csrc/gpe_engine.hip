@@ -577,9 +577,15 @@ static int mlp_forward(gpe_engine* e, Batch& b, bool store) {
         for (int lin = 0; lin < nd.n_lin; ++lin) {
             const float* Sprev = lin > 0 ? b.S[lin - 1] : nullptr;
             float* Out = (lin == nd.n_lin - 1) ? b.O : b.S[lin];
-            dim3 grid(cdiv(b.n, 256), cdiv(nd.width[lin + 1], G_FB));
-            DISPATCH_FWD(b, hipLaunchKernelGGL((g_fwd_layer<CC, EE>), grid, dim3(256), 0, e->stream, nd, lin, e->theta, b.pts,
-                                                Sprev, Out, b.n, b.ld));
+            if (nd.width[lin + 1] >= 64) {      // wide layer: 16 output features per thread
+                dim3 grid(cdiv(b.n, 256), cdiv(nd.width[lin + 1], G_FBW));
+                DISPATCH_FWD(b, hipLaunchKernelGGL((g_fwd_layer<CC, EE, G_FBW>), grid, dim3(256), 0, e->stream, nd, lin, e->theta,
+                                                    b.pts, Sprev, Out, b.n, b.ld));
+            } else {
+                dim3 grid(cdiv(b.n, 256), cdiv(nd.width[lin + 1], G_FB));
+                DISPATCH_FWD(b, hipLaunchKernelGGL((g_fwd_layer<CC, EE, G_FB>), grid, dim3(256), 0, e->stream, nd, lin, e->theta,
+                                                    b.pts, Sprev, Out, b.n, b.ld));
+            }
         }
     }
     HIPCHK(e, hipGetLastError());
@@ -646,13 +652,25 @@ static int mlp_backward(gpe_engine* e, Batch& b, bool close = false, bool assign
         for (int lin = nd.n_lin - 1; lin >= 0; --lin) {
             const int K = nd.width[lin], Ho = nd.width[lin + 1];
             const float* Sprev = lin > 0 ? b.S[lin - 1] : nullptr;
-            dim3 gw(Ho, cdiv(K, G_KB));
-            DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_weight<CC, EE>), gw, dim3(256), 0, e->stream, nd, lin, b.pts, Sprev, Zb,
-                                                e->grad, b.n, b.ld));
+            if (Ho >= 64) {                     // wide layer: 8 rows of the weight gradient per block share the recomputed jets
+                dim3 gw(cdiv(Ho, 8), cdiv(K, G_KB));
+                DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_weight<CC, EE, 8>), gw, dim3(256), 0, e->stream, nd, lin, b.pts, Sprev,
+                                                    Zb, e->grad, b.n, b.ld));
+            } else {
+                dim3 gw(Ho, cdiv(K, G_KB));
+                DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_weight<CC, EE, 1>), gw, dim3(256), 0, e->stream, nd, lin, b.pts, Sprev,
+                                                    Zb, e->grad, b.n, b.ld));
+            }
             if (lin > 0) {
-                dim3 gd(cdiv(b.n, 256), cdiv(K, G_FB));
-                DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_data<CC>), gd, dim3(256), 0, e->stream, nd, lin, e->theta, Zb,
-                                                    nxt, b.n, b.ld));
+                if (K >= 64) {
+                    dim3 gd(cdiv(b.n, 256), cdiv(K, G_FBW));
+                    DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_data<CC, G_FBW>), gd, dim3(256), 0, e->stream, nd, lin, e->theta, Zb,
+                                                        nxt, b.n, b.ld));
+                } else {
+                    dim3 gd(cdiv(b.n, 256), cdiv(K, G_FB));
+                    DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_data<CC, G_FB>), gd, dim3(256), 0, e->stream, nd, lin, e->theta, Zb,
+                                                        nxt, b.n, b.ld));
+                }
                 dim3 ga(cdiv(b.n, 256), K);
                 DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_act<CC, EE>), ga, dim3(256), 0, e->stream, K, Sprev, nxt, b.n, b.ld));
                 Zb = nxt;

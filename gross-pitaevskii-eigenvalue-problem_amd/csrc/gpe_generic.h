@@ -10,11 +10,13 @@
 #pragma once
 #include "gpe_common.h"
 
-#define G_FB 4   // output features per thread
+#define G_FB 4   // output features per thread (narrow layers)
+#define G_FBW 16 // output features per thread for layers at least 64 wide: the activation recompute and the input loads of a
+                 // point are shared by 16 outputs instead of 4 (cfg5: the layer kernels were recompute- and load-bound)
 
 // lin: index of the linear map.  Sprev: stored of hidden layer lin-1 (NULL for lin==0).  Out: stored of hidden
 // layer lin, or the output jets O when lin == n_lin-1.
-template <int C, int E>
+template <int C, int E, int FB>
 __global__ __launch_bounds__(256) void g_fwd_layer(NetDesc nd, int lin, const float* __restrict__ theta,
                                                    Pts x, const float* __restrict__ Sprev,
                                                    float* __restrict__ Out, int64_t N, int64_t ld) {
@@ -22,12 +24,12 @@ __global__ __launch_bounds__(256) void g_fwd_layer(NetDesc nd, int lin, const fl
     int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (m >= N) return;
     const int K = nd.width[lin], Ho = nd.width[lin + 1];
-    const int n0 = blockIdx.y * G_FB;
+    const int n0 = blockIdx.y * FB;
     const float* W = theta + nd.offW[lin];
     const float* b = theta + nd.offB[lin];
-    float acc[G_FB][C];
+    float acc[FB][C];
 #pragma unroll
-    for (int f = 0; f < G_FB; ++f) {
+    for (int f = 0; f < FB; ++f) {
         int n = min(n0 + f, Ho - 1);
         acc[f][0] = b[n];
 #pragma unroll
@@ -37,7 +39,7 @@ __global__ __launch_bounds__(256) void g_fwd_layer(NetDesc nd, int lin, const fl
         for (int k = 0; k < K; ++k) {
             float xk = pts_at(x, m, K, k);
 #pragma unroll
-            for (int f = 0; f < G_FB; ++f) {
+            for (int f = 0; f < FB; ++f) {
                 int n = min(n0 + f, Ho - 1);
                 float w = W[n * K + k];
                 acc[f][0] = fmaf(w, xk, acc[f][0]);
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(256) void g_fwd_layer(NetDesc nd, int lin, const fl
             for (int j = 0; j < E; ++j) zkk[j] = Sprev[((int64_t)(1 + D + j) * K + k) * ld + m];
             act_from_stored<D, E>(t, zk, zkk, nd.shift, a);
 #pragma unroll
-            for (int f = 0; f < G_FB; ++f) {
+            for (int f = 0; f < FB; ++f) {
                 int n = min(n0 + f, Ho - 1);
                 float w = W[n * K + k];
 #pragma unroll
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(256) void g_fwd_layer(NetDesc nd, int lin, const fl
     }
     const bool last = (lin == nd.n_lin - 1);
 #pragma unroll
-    for (int f = 0; f < G_FB; ++f) {
+    for (int f = 0; f < FB; ++f) {
         int n = n0 + f;
         if (n >= Ho) break;
         if (!last) acc[f][0] = gpe_tanh(acc[f][0]);
@@ -98,18 +100,18 @@ __global__ __launch_bounds__(256) void g_bwd_act(int H, const float* __restrict_
 }
 
 // Aprev[c][k][m] = sum_n W[n][k] Zb[c][n][m].   grid (ceil(N/256), ceil(K/G_FB)).
-template <int C>
+template <int C, int FB>
 __global__ __launch_bounds__(256) void g_bwd_data(NetDesc nd, int lin, const float* __restrict__ theta,
                                                   const float* __restrict__ Zb, float* __restrict__ Aprev, int64_t N,
                                                   int64_t ld) {
     int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (m >= N) return;
     const int K = nd.width[lin], Ho = nd.width[lin + 1];
-    const int k0 = blockIdx.y * G_FB;
+    const int k0 = blockIdx.y * FB;
     const float* W = theta + nd.offW[lin];
-    float acc[G_FB][C];
+    float acc[FB][C];
 #pragma unroll
-    for (int f = 0; f < G_FB; ++f)
+    for (int f = 0; f < FB; ++f)
 #pragma unroll
         for (int c = 0; c < C; ++c) acc[f][c] = 0.f;
     for (int n = 0; n < Ho; ++n) {
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(256) void g_bwd_data(NetDesc nd, int lin, const flo
 #pragma unroll
         for (int c = 0; c < C; ++c) z[c] = Zb[((int64_t)c * Ho + n) * ld + m];
 #pragma unroll
-        for (int f = 0; f < G_FB; ++f) {
+        for (int f = 0; f < FB; ++f) {
             int k = min(k0 + f, K - 1);
             float w = W[n * K + k];
 #pragma unroll
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256) void g_bwd_data(NetDesc nd, int lin, const flo
         }
     }
 #pragma unroll
-    for (int f = 0; f < G_FB; ++f) {
+    for (int f = 0; f < FB; ++f) {
         int k = k0 + f;
         if (k >= K) break;
 #pragma unroll
@@ -134,36 +136,50 @@ __global__ __launch_bounds__(256) void g_bwd_data(NetDesc nd, int lin, const flo
 }
 
 // grad W[n][k] += sum_{c,m} Zb[c][n][m] * A[c][k][m],  grad b[n] += sum_m Zb[0][n][m].
-// One block per (n, 16-wide k block); the block walks all points -> deterministic, no atomics.
+// One block per (NB-row block of n, 16-wide k block); the block walks all points -> deterministic, no atomics.  The activation
+// jets A of a point are recomputed once per k and shared by the NB rows (NB = 8 for wide layers: with one row per block the
+// kernel recomputed them Ho times and was 64 % of a cfg5 step).
 #define G_KB 16
-template <int C, int E>
+template <int C, int E, int NB>
 __global__ __launch_bounds__(256) void g_bwd_weight(NetDesc nd, int lin, Pts x,
                                                     const float* __restrict__ Sprev, const float* __restrict__ Zb,
                                                     float* __restrict__ grad, int64_t N, int64_t ld) {
     constexpr int D = C - 1 - E;
     __shared__ double red[4];
     const int K = nd.width[lin], Ho = nd.width[lin + 1];
-    const int n = blockIdx.x, k0 = blockIdx.y * G_KB;
-    float p[G_KB];
+    const int n0 = blockIdx.x * NB, k0 = blockIdx.y * G_KB;
+    float p[NB][G_KB];
+    float pb[NB];
 #pragma unroll
-    for (int i = 0; i < G_KB; ++i) p[i] = 0.f;
-    float pb = 0.f;
+    for (int r = 0; r < NB; ++r) {
+        pb[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < G_KB; ++i) p[r][i] = 0.f;
+    }
     for (int64_t m = threadIdx.x; m < N; m += 256) {
-        float z[C];
+        float z[NB][C];
 #pragma unroll
-        for (int c = 0; c < C; ++c) z[c] = Zb[((int64_t)c * Ho + n) * ld + m];
-        pb += z[0];
+        for (int r = 0; r < NB; ++r) {
+            const int n = min(n0 + r, Ho - 1);
+#pragma unroll
+            for (int c = 0; c < C; ++c) z[r][c] = Zb[((int64_t)c * Ho + n) * ld + m];
+            pb[r] += z[r][0];
+        }
 #pragma unroll
         for (int i = 0; i < G_KB; ++i) {
             int k = k0 + i;
             if (k >= K) break;
             if (lin == 0) {
-                float v = z[0] * pts_at(x, m, K, k);
-                if (C > 1) {
+                const float xk = pts_at(x, m, K, k);
 #pragma unroll
-                    for (int j = 0; j < D; ++j) if (j == k) v += z[1 + j];
+                for (int r = 0; r < NB; ++r) {
+                    float v = z[r][0] * xk;
+                    if (C > 1) {
+#pragma unroll
+                        for (int j = 0; j < D; ++j) if (j == k) v += z[r][1 + j];
+                    }
+                    p[r][i] += v;
                 }
-                p[i] += v;
             } else {
                 float t = Sprev[((int64_t)0 * K + k) * ld + m];
                 float zk[D > 0 ? D : 1], zkk[E > 0 ? E : 1], a[C];
@@ -172,21 +188,29 @@ __global__ __launch_bounds__(256) void g_bwd_weight(NetDesc nd, int lin, Pts x,
 #pragma unroll
                 for (int j = 0; j < E; ++j) zkk[j] = Sprev[((int64_t)(1 + D + j) * K + k) * ld + m];
                 act_from_stored<D, E>(t, zk, zkk, nd.shift, a);
-                float v = 0.f;
 #pragma unroll
-                for (int c = 0; c < C; ++c) v = fmaf(z[c], a[c], v);
-                p[i] += v;
+                for (int r = 0; r < NB; ++r) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) v = fmaf(z[r][c], a[c], v);
+                    p[r][i] += v;
+                }
             }
         }
     }
-    for (int i = 0; i < G_KB; ++i) {
-        int k = k0 + i;
-        if (k >= K) break;
-        double r = block_sum_256((double)p[i], red);
-        if (threadIdx.x == 0) grad[nd.offW[lin] + n * K + k] += (float)r;
-    }
-    if (blockIdx.y == 0) {
-        double r = block_sum_256((double)pb, red);
-        if (threadIdx.x == 0) grad[nd.offB[lin] + n] += (float)r;
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+        const int n = n0 + r;
+        if (n >= Ho) break;
+        for (int i = 0; i < G_KB; ++i) {
+            int k = k0 + i;
+            if (k >= K) break;
+            double s = block_sum_256((double)p[r][i], red);
+            if (threadIdx.x == 0) grad[nd.offW[lin] + n * K + k] += (float)s;
+        }
+        if (blockIdx.y == 0) {
+            double s = block_sum_256((double)pb[r], red);
+            if (threadIdx.x == 0) grad[nd.offB[lin] + n] += (float)s;
+        }
     }
 }
