@@ -654,11 +654,15 @@ static int mlp_backward(gpe_engine* e, Batch& b, bool close = false, bool assign
             const float* Sprev = lin > 0 ? b.S[lin - 1] : nullptr;
             if (Ho >= 64) {                     // wide layer: 8 rows of the weight gradient per block share the recomputed jets
                 dim3 gw(cdiv(Ho, 8), cdiv(K, G_KB));
-                DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_weight<CC, EE, 8>), gw, dim3(256), 0, e->stream, nd, lin, b.pts, Sprev,
+                DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_weight<CC, EE, 8, G_KB>), gw, dim3(256), 0, e->stream, nd, lin, b.pts, Sprev,
+                                                    Zb, e->grad, b.n, b.ld));
+            } else if (Ho < 8 && K >= 64) {     // output layer of a wide network: one block per (n, k) keeps K blocks in flight
+                dim3 gw(Ho, K);
+                DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_weight<CC, EE, 1, 1>), gw, dim3(256), 0, e->stream, nd, lin, b.pts, Sprev,
                                                     Zb, e->grad, b.n, b.ld));
             } else {
                 dim3 gw(Ho, cdiv(K, G_KB));
-                DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_weight<CC, EE, 1>), gw, dim3(256), 0, e->stream, nd, lin, b.pts, Sprev,
+                DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_weight<CC, EE, 1, G_KB>), gw, dim3(256), 0, e->stream, nd, lin, b.pts, Sprev,
                                                     Zb, e->grad, b.n, b.ld));
             }
             if (lin > 0) {

@@ -139,22 +139,23 @@ __global__ __launch_bounds__(256) void g_bwd_data(NetDesc nd, int lin, const flo
 // One block per (NB-row block of n, 16-wide k block); the block walks all points -> deterministic, no atomics.  The activation
 // jets A of a point are recomputed once per k and shared by the NB rows (NB = 8 for wide layers: with one row per block the
 // kernel recomputed them Ho times and was 64 % of a cfg5 step).
+// Narrow outputs (Ho < 8, the output layer): KB = 1, one block per (n, k), so that the grid still has K blocks.
 #define G_KB 16
-template <int C, int E, int NB>
+template <int C, int E, int NB, int KB>
 __global__ __launch_bounds__(256) void g_bwd_weight(NetDesc nd, int lin, Pts x,
                                                     const float* __restrict__ Sprev, const float* __restrict__ Zb,
                                                     float* __restrict__ grad, int64_t N, int64_t ld) {
     constexpr int D = C - 1 - E;
     __shared__ double red[4];
     const int K = nd.width[lin], Ho = nd.width[lin + 1];
-    const int n0 = blockIdx.x * NB, k0 = blockIdx.y * G_KB;
-    float p[NB][G_KB];
+    const int n0 = blockIdx.x * NB, k0 = blockIdx.y * KB;
+    float p[NB][KB];
     float pb[NB];
 #pragma unroll
     for (int r = 0; r < NB; ++r) {
         pb[r] = 0.f;
 #pragma unroll
-        for (int i = 0; i < G_KB; ++i) p[r][i] = 0.f;
+        for (int i = 0; i < KB; ++i) p[r][i] = 0.f;
     }
     for (int64_t m = threadIdx.x; m < N; m += 256) {
         float z[NB][C];
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256) void g_bwd_weight(NetDesc nd, int lin, Pts x,
             pb[r] += z[r][0];
         }
 #pragma unroll
-        for (int i = 0; i < G_KB; ++i) {
+        for (int i = 0; i < KB; ++i) {
             int k = k0 + i;
             if (k >= K) break;
             if (lin == 0) {
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(256) void g_bwd_weight(NetDesc nd, int lin, Pts x,
     for (int r = 0; r < NB; ++r) {
         const int n = n0 + r;
         if (n >= Ho) break;
-        for (int i = 0; i < G_KB; ++i) {
+        for (int i = 0; i < KB; ++i) {
             int k = k0 + i;
             if (k >= K) break;
             double s = block_sum_256((double)p[r][i], red);
