@@ -228,6 +228,7 @@ struct gpe_engine {
     int coop = 1;                                 // cooperative reverse kernel: 0 never, 1 whenever compiled for the shape, -1 by batch size
     int64_t coop_max_tiles = 0;
     bool coop_fwd128 = true;
+    bool gen_mfma = true;                         // generic path: MFMA split-K weight gradient for wide layers
     bool coop128 = true;                          // H = 128: use the cooperative reverse kernel (else global-atomic slabs)
     int64_t coop_fwd_max_tiles = 0;               // forward: cooperative kernel for batches up to this many tiles
     int64_t stage_min_tiles = 0;                  // batches with fewer 16-point tiles use the unstaged kernels (latency-bound regime)
@@ -652,7 +653,16 @@ static int mlp_backward(gpe_engine* e, Batch& b, bool close = false, bool assign
         for (int lin = nd.n_lin - 1; lin >= 0; --lin) {
             const int K = nd.width[lin], Ho = nd.width[lin + 1];
             const float* Sprev = lin > 0 ? b.S[lin - 1] : nullptr;
-            if (Ho >= 64) {                     // wide layer: 8 rows of the weight gradient per block share the recomputed jets
+            if (lin > 0 && Ho % 64 == 0 && K % 64 == 0 && e->gen_mfma) {
+                // wide hidden->hidden map: split-K GEMM over the points on the matrix cores
+                const int64_t want = (int64_t)e->num_cu * 16 / ((Ho / 64) * (K / 64)) + 1;          // chunks so that ~16 waves per CU exist
+                int64_t chunk = ((b.n + want - 1) / want + 15) / 16 * 16;
+                if (chunk < 256) chunk = 256;
+                const int64_t nchunk = (b.n + chunk - 1) / chunk;
+                dim3 gw(Ho / 64, K / 64, (unsigned)((nchunk + 3) / 4));
+                DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_weight_mfma<CC, EE>), gw, dim3(256), 0, e->stream, nd, lin, Sprev, Zb,
+                                                    e->grad, b.n, b.ld, chunk));
+            } else if (Ho >= 64) {              // wide layer: 8 rows of the weight gradient per block share the recomputed jets
                 dim3 gw(cdiv(Ho, 8), cdiv(K, G_KB));
                 DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_weight<CC, EE, 8, G_KB>), gw, dim3(256), 0, e->stream, nd, lin, b.pts, Sprev,
                                                     Zb, e->grad, b.n, b.ld));
@@ -888,6 +898,8 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
     if (ok) {
         ok = alloc((void**)&e->grad_bc, (size_t)e->P * 4);
         if (ok && e->path == GPE_PATH_FUSED) ok = alloc((void**)&e->gslab_bc, (size_t)e->nslab * e->Ppad * 4);
+        const char* envm2 = getenv("GPE_GEN_MFMA");
+        e->gen_mfma = !envm2 || atoi(envm2) != 0;
         const char* envb = getenv("GPE_MERGE_BC");
         e->merge_bc = !envb || atoi(envb) != 0;
         const char* envg = getenv("GPE_GRAPH");

@@ -215,3 +215,97 @@ __global__ __launch_bounds__(256) void g_bwd_weight(NetDesc nd, int lin, Pts x,
         }
     }
 }
+
+// ---- weight gradient of a wide hidden->hidden map on the matrix cores ------------------------------------------------------
+// dW[n][k] += sum_c sum_m Zb[c][n][m] A_c[k][m]  is a GEMM with the POINTS as the contraction index.  The generic set's buffers
+// are feature-major with the point index contiguous, so both MFMA operands of v_mfma_f32_16x16x4_f32 come straight from global
+// memory as float4 loads (lane (i, kq): row n0+i resp. k0+i, points m0+4kq..m0+4kq+3; element s of the float4 is the k-slot of
+// the s-th of four MFMAs) -- no LDS, no transposes.  One wave owns a 64 x 64 block of dW (16 accumulator tiles) and a chunk of
+// the points (split-K); the activation jets A are recomputed per wave from the stored (t, z_k, z_L).  Partial blocks are added to
+// the gradient with float atomics (the one place where the generic set is not bitwise reproducible).
+// grid (Ho/64, K/64, chunks/4), block 256 = 4 waves on consecutive chunks.  Needs Ho % 64 == 0, K % 64 == 0, lin >= 1.
+typedef float g_f32x4 __attribute__((ext_vector_type(4)));
+template <int C, int E>
+__global__ __launch_bounds__(256, 1) void g_bwd_weight_mfma(NetDesc nd, int lin, const float* __restrict__ Sprev,
+                                                           const float* __restrict__ Zb, float* __restrict__ grad, int64_t N,
+                                                           int64_t ld, int64_t chunk) {
+    constexpr int D = C - 1 - E;
+    const int K = nd.width[lin], Ho = nd.width[lin + 1];
+    const int lane = threadIdx.x & 63, i = lane & 15, kq = lane >> 4, w = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+    const int64_t c0 = ((int64_t)blockIdx.z * 4 + w) * chunk;
+    const int64_t c1 = min(c0 + chunk, N);
+    if (c0 >= N) return;                              // no barriers in this kernel
+    g_f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (g_f32x4){0.f, 0.f, 0.f, 0.f};
+    float pb[4] = {0.f, 0.f, 0.f, 0.f};
+    auto ld4 = [&](const float* base, int64_t m) -> g_f32x4 {          // 4 consecutive points, zero past the end (ld is a multiple of 64)
+        g_f32x4 v = *reinterpret_cast<const g_f32x4*>(base + m);
+        if (m + 3 >= c1) {
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) if (m + s2 >= c1) v[s2] = 0.f;
+        }
+        return v;
+    };
+    for (int64_t m0 = c0; m0 < c1; m0 += 16) {
+        const int64_t m = m0 + 4 * kq;
+        // activation jets of the 4 K tiles at this lane's 4 points
+        g_f32x4 a[4][C];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const int k = k0 + 16 * kt + i;
+            g_f32x4 st[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) st[c] = *reinterpret_cast<const g_f32x4*>(Sprev + ((int64_t)c * K + k) * ld + m);
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                float zk[D > 0 ? D : 1], zkk[E > 0 ? E : 1], av[C];
+#pragma unroll
+                for (int j = 0; j < D; ++j) zk[j] = st[1 + j][s2];
+#pragma unroll
+                for (int j = 0; j < E; ++j) zkk[j] = st[1 + D + j][s2];
+                act_from_stored<D, E>(st[0][s2], zk, zkk, nd.shift, av);
+#pragma unroll
+                for (int c = 0; c < C; ++c) a[kt][c][s2] = av[c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            g_f32x4 za[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) za[nt] = ld4(Zb + ((int64_t)c * Ho + n0 + 16 * nt + i) * ld, m);
+            if (c == 0) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) pb[nt] += (za[nt][0] + za[nt][1]) + (za[nt][2] + za[nt][3]);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+                        acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[nt][s2], a[kt][c][s2], acc[nt][kt], 0, 0, 0);
+        }
+    }
+    // D layout: lane (col = i, q = kq), element r <-> row 4q + r
+    float* gW = grad + nd.offW[lin];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                atomicAdd(&gW[(int64_t)(n0 + 16 * nt + 4 * kq + r) * K + k0 + 16 * kt + i], acc[nt][kt][r]);
+    if (blockIdx.y == 0) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            float v = pb[nt];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (kq == 0) atomicAdd(&grad[nd.offB[lin] + n0 + 16 * nt + i], v);
+        }
+    }
+}
