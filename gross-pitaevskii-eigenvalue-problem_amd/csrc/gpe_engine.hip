@@ -578,7 +578,11 @@ static int mlp_forward(gpe_engine* e, Batch& b, bool store) {
         for (int lin = 0; lin < nd.n_lin; ++lin) {
             const float* Sprev = lin > 0 ? b.S[lin - 1] : nullptr;
             float* Out = (lin == nd.n_lin - 1) ? b.O : b.S[lin];
-            if (nd.width[lin + 1] >= 64) {      // wide layer: 16 output features per thread
+            if (lin > 0 && nd.width[lin] % 64 == 0 && nd.width[lin + 1] % 64 == 0 && e->gen_mfma) {   // wide map: matrix cores
+                dim3 grid(cdiv(cdiv(b.n, 16), 4), nd.width[lin + 1] / 64);
+                DISPATCH_FWD(b, hipLaunchKernelGGL((g_fwd_layer_mfma<CC, EE>), grid, dim3(256), 0, e->stream, nd, lin, e->theta,
+                                                    Sprev, Out, b.n, b.ld));
+            } else if (nd.width[lin + 1] >= 64) {      // wide layer: 16 output features per thread
                 dim3 grid(cdiv(b.n, 256), cdiv(nd.width[lin + 1], G_FBW));
                 DISPATCH_FWD(b, hipLaunchKernelGGL((g_fwd_layer<CC, EE, G_FBW>), grid, dim3(256), 0, e->stream, nd, lin, e->theta,
                                                     b.pts, Sprev, Out, b.n, b.ld));
@@ -676,7 +680,11 @@ static int mlp_backward(gpe_engine* e, Batch& b, bool close = false, bool assign
                                                     Zb, e->grad, b.n, b.ld));
             }
             if (lin > 0) {
-                if (K >= 64) {
+                if (K % 64 == 0 && Ho % 16 == 0 && e->gen_mfma) {
+                    dim3 gd(cdiv(cdiv(b.n, 16), 4), K / 64);
+                    DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_data_mfma<CC>), gd, dim3(256), 0, e->stream, nd, lin, e->theta, Zb,
+                                                        nxt, b.n, b.ld));
+                } else if (K >= 64) {
                     dim3 gd(cdiv(b.n, 256), cdiv(K, G_FBW));
                     DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_data<CC, G_FBW>), gd, dim3(256), 0, e->stream, nd, lin, e->theta, Zb,
                                                         nxt, b.n, b.ld));

@@ -309,3 +309,113 @@ __global__ __launch_bounds__(256, 1) void g_bwd_weight_mfma(NetDesc nd, int lin,
         }
     }
 }
+
+// ---- wide layers on the matrix cores: forward map and adjoint map ----------------------------------------------------------
+// Same idea as g_bwd_weight_mfma: with feature-major buffers (point index contiguous) the operands of v_mfma_f32_16x16x4_f32 are
+// plain global loads.  One wave = one 16-point tile x 64 output features (4 accumulator tiles per channel).
+//   forward:  Out[c][n][m] = sum_k W[n][k] A_c[k][m] (+ b[n] on the value channel), tanh on the value channel of hidden layers;
+//             A = W rows (float4 along k), B = activation jets recomputed from the stored (t, z_k, z_L) of the previous layer
+//   adjoint:  Aprev[c][k][m] = sum_n W[n][k] Zb[c][n][m];  A = W^T (scalar loads, lanes along k), B = Zb
+// grid (ceil(N/16/4), Ho/64) resp. (ceil(N/16/4), K/64), block 256 = 4 waves on consecutive point tiles.
+// Needs: both widths multiples of 64, lin >= 1.
+template <int C, int E>
+__global__ __launch_bounds__(256) void g_fwd_layer_mfma(NetDesc nd, int lin, const float* __restrict__ theta,
+                                                        const float* __restrict__ Sprev, float* __restrict__ Out, int64_t N,
+                                                        int64_t ld) {
+    constexpr int D = C - 1 - E;
+    const int K = nd.width[lin], Ho = nd.width[lin + 1];
+    const int lane = threadIdx.x & 63, i = lane & 15, kq = lane >> 4, w = threadIdx.x >> 6;
+    const int64_t m0 = ((int64_t)blockIdx.x * 4 + w) * 16;
+    if (m0 >= N) return;
+    const int n0 = blockIdx.y * 64;
+    const float* W = theta + nd.offW[lin];
+    const float* bias = theta + nd.offB[lin];
+    const int64_t mp = m0 + i;                                   // this lane's point as B-operand column / D column
+    g_f32x4 acc[4][C];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        acc[nt][0] = *reinterpret_cast<const g_f32x4*>(&bias[n0 + 16 * nt + 4 * kq]);
+#pragma unroll
+        for (int c = 1; c < C; ++c) acc[nt][c] = (g_f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        g_f32x4 wv[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) wv[nt] = *reinterpret_cast<const g_f32x4*>(&W[(int64_t)(n0 + 16 * nt + i) * K + k0 + 4 * kq]);
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            const int k = k0 + 4 * kq + s2;
+            float zk[D > 0 ? D : 1], zkk[E > 0 ? E : 1], a[C];
+            const float t = Sprev[((int64_t)0 * K + k) * ld + mp];
+#pragma unroll
+            for (int j = 0; j < D; ++j) zk[j] = Sprev[((int64_t)(1 + j) * K + k) * ld + mp];
+#pragma unroll
+            for (int j = 0; j < E; ++j) zkk[j] = Sprev[((int64_t)(1 + D + j) * K + k) * ld + mp];
+            act_from_stored<D, E>(t, zk, zkk, nd.shift, a);
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[nt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nt][s2], a[c], acc[nt][c], 0, 0, 0);
+        }
+    }
+    const bool last = (lin == nd.n_lin - 1);
+    if (mp < N) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + 16 * nt + 4 * kq + r;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    float v = acc[nt][c][r];
+                    if (c == 0 && !last) v = gpe_tanh(v);
+                    Out[((int64_t)c * Ho + n) * ld + mp] = v;
+                }
+            }
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void g_bwd_data_mfma(NetDesc nd, int lin, const float* __restrict__ theta,
+                                                       const float* __restrict__ Zb, float* __restrict__ Aprev, int64_t N,
+                                                       int64_t ld) {
+    const int K = nd.width[lin], Ho = nd.width[lin + 1];
+    const int lane = threadIdx.x & 63, i = lane & 15, kq = lane >> 4, w = threadIdx.x >> 6;
+    const int64_t m0 = ((int64_t)blockIdx.x * 4 + w) * 16;
+    if (m0 >= N) return;
+    const int k0 = blockIdx.y * 64;
+    const float* W = theta + nd.offW[lin];
+    const int64_t mp = m0 + i;
+    g_f32x4 acc[4][C];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[kt][c] = (g_f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int n0 = 0; n0 < Ho; n0 += 16) {
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            const int n = n0 + 4 * kq + s2;
+            float wv[4], z[C];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) wv[kt] = W[(int64_t)n * K + k0 + 16 * kt + i];
+#pragma unroll
+            for (int c = 0; c < C; ++c) z[c] = Zb[((int64_t)c * Ho + n) * ld + mp];
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+                    acc[kt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[kt], z[c], acc[kt][c], 0, 0, 0);
+        }
+    }
+    if (mp < N) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = k0 + 16 * kt + 4 * kq + r;
+#pragma unroll
+                for (int c = 0; c < C; ++c) Aprev[((int64_t)c * K + k) * ld + mp] = acc[kt][c][r];
+            }
+    }
+}
