@@ -238,11 +238,11 @@ def main():
             "step_flop_per_point": flops_pt, "whole_step_tflops": flops_pt * value / world / 1e12,
             "b_mat_bytes_per_point": bmat_pt, "b_mat_gbps": bmat_pt * value / world / 1e9,
         }
-        if not fused:       # layer-materialised VALU kernels: bound by the activation traffic model B_mat (no per-kernel events)
-            gbps = bmat_pt * value / world / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": "generic layer-wise set (g_fwd_layer / g_bwd_*), whole step", "achieved": gbps,
-                               "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0, "traffic": None,
-                               "algorithmic_bytes_per_launch": bmat_pt * n_local, "avg_launch_ms": elapsed / args.steps * 1e3}
+        if not fused:       # layer-wise generic set (MFMA maps for wide layers): no per-kernel events, the whole step is rated
+            tf = flops_pt * value / world / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "generic layer-wise set (g_*_mfma maps + VALU head/activation kernels), whole step",
+                               "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS,
+                               "traffic": None, "algorithmic_flop_per_point": flops_pt, "avg_launch_ms": elapsed / args.steps * 1e3}
             out.pop("roofline_forward", None)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, flat)

@@ -666,7 +666,7 @@ static int mlp_backward(gpe_engine* e, Batch& b, bool close = false, bool assign
                 dim3 gw(Ho / 64, K / 64, (unsigned)((nchunk + 3) / 4));
                 DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_weight_mfma<CC, EE>), gw, dim3(256), 0, e->stream, nd, lin, Sprev, Zb,
                                                     e->grad, b.n, b.ld, chunk));
-            } else if (Ho >= 64) {              // wide layer: 8 rows of the weight gradient per block share the recomputed jets
+            } else if (Ho >= 64 && K >= 16) {   // wide layer: 8 rows of the weight gradient per block share the recomputed jets
                 dim3 gw(cdiv(Ho, 8), cdiv(K, G_KB));
                 DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_weight<CC, EE, 8, G_KB>), gw, dim3(256), 0, e->stream, nd, lin, b.pts, Sprev,
                                                     Zb, e->grad, b.n, b.ld));
