@@ -228,6 +228,7 @@ struct gpe_engine {
     int coop = 1;                                 // cooperative reverse kernel: 0 never, 1 whenever compiled for the shape, -1 by batch size
     int64_t coop_max_tiles = 0;
     bool coop_fwd128 = true;
+    bool gen_mfma2 = true;                        // ... with 128 x 128 block tiles and LDS-shared operand panels
     bool gen_mfma = true;                         // generic path: MFMA split-K weight gradient for wide layers
     bool coop128 = true;                          // H = 128: use the cooperative reverse kernel (else global-atomic slabs)
     int64_t coop_fwd_max_tiles = 0;               // forward: cooperative kernel for batches up to this many tiles
@@ -657,7 +658,17 @@ static int mlp_backward(gpe_engine* e, Batch& b, bool close = false, bool assign
         for (int lin = nd.n_lin - 1; lin >= 0; --lin) {
             const int K = nd.width[lin], Ho = nd.width[lin + 1];
             const float* Sprev = lin > 0 ? b.S[lin - 1] : nullptr;
-            if (lin > 0 && Ho % 64 == 0 && K % 64 == 0 && e->gen_mfma) {
+            if (lin > 0 && Ho % 128 == 0 && K % 128 == 0 && e->gen_mfma && e->gen_mfma2) {
+                // wide hidden->hidden map, 128 x 128 block tiles with LDS-shared operand panels
+                const int64_t want = (int64_t)e->num_cu * 4 / ((Ho / 128) * (K / 128)) + 1;       // ~4 blocks per CU
+                int64_t chunk = ((b.n + want - 1) / want + 15) / 16 * 16;
+                if (chunk < 256) chunk = 256;
+                const int64_t nchunk = (b.n + chunk - 1) / chunk;
+                dim3 gw(Ho / 128, K / 128, (unsigned)nchunk);
+                const size_t pl = (size_t)2 * b.C * 128 * 16 * sizeof(float);
+                DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_weight_mfma2<CC, EE>), gw, dim3(256), pl, e->stream, nd, lin, Sprev, Zb,
+                                                    e->grad, b.n, b.ld, chunk));
+            } else if (lin > 0 && Ho % 64 == 0 && K % 64 == 0 && e->gen_mfma) {
                 // wide hidden->hidden map: split-K GEMM over the points on the matrix cores
                 const int64_t want = (int64_t)e->num_cu * 16 / ((Ho / 64) * (K / 64)) + 1;          // chunks so that ~16 waves per CU exist
                 int64_t chunk = ((b.n + want - 1) / want + 15) / 16 * 16;
@@ -908,6 +919,17 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
         if (ok && e->path == GPE_PATH_FUSED) ok = alloc((void**)&e->gslab_bc, (size_t)e->nslab * e->Ppad * 4);
         const char* envm2 = getenv("GPE_GEN_MFMA");
         e->gen_mfma = !envm2 || atoi(envm2) != 0;
+        const char* envm3 = getenv("GPE_GEN_MFMA2");
+        e->gen_mfma2 = !envm3 || atoi(envm3) != 0;
+#ifndef GPE_FAST_BUILD
+        (void)hipFuncSetAttribute((const void*)g_bwd_weight_mfma2<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)g_bwd_weight_mfma2<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)g_bwd_weight_mfma2<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)g_bwd_weight_mfma2<5, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#else
+        (void)hipFuncSetAttribute((const void*)g_bwd_weight_mfma2<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)g_bwd_weight_mfma2<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#endif
         const char* envb = getenv("GPE_MERGE_BC");
         e->merge_bc = !envb || atoi(envb) != 0;
         const char* envg = getenv("GPE_GRAPH");

@@ -419,3 +419,102 @@ __global__ __launch_bounds__(256) void g_bwd_data_mfma(NetDesc nd, int lin, cons
             }
     }
 }
+
+// Block-cooperative version of g_bwd_weight_mfma: the 4 waves of a block own a 2 x 2 arrangement of 64 x 64 blocks of dW
+// (128 x 128 per block) and walk the SAME point chunk; per 16-point step every wave loads / recomputes a quarter of the two operand
+// panels (128 rows of Zb, the activation jets of 128 input features) into LDS, so the panels are fetched from L2 and recomputed once
+// per block instead of once per wave: half the L2 traffic and a quarter of the recompute per MFMA.
+// grid (Ho/128, K/128, chunks), block 256.  Needs Ho % 128 == 0, K % 128 == 0, lin >= 1.  LDS: 2 panels x C x 128 x 16 floats.
+template <int C, int E>
+__global__ __launch_bounds__(256, 1) void g_bwd_weight_mfma2(NetDesc nd, int lin, const float* __restrict__ Sprev,
+                                                            const float* __restrict__ Zb, float* __restrict__ grad, int64_t N,
+                                                            int64_t ld, int64_t chunk) {
+    constexpr int D = C - 1 - E;
+    extern __shared__ __attribute__((aligned(16))) float g_panels[];   // dynamic: 2 * C * 128 * 16 floats (80 KB for C = 5)
+    float (*PZ)[128][16] = reinterpret_cast<float (*)[128][16]>(g_panels);                    // Zb panel:  [channel][row n][point]
+    float (*PA)[128][16] = reinterpret_cast<float (*)[128][16]>(g_panels + C * 128 * 16);     // jets panel: [channel][col k][point]
+    const int K = nd.width[lin], Ho = nd.width[lin + 1];
+    const int lane = threadIdx.x & 63, i = lane & 15, kq = lane >> 4, w = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
+    const int wn = (w >> 1) * 64, wk = (w & 1) * 64;                   // this wave's 64 x 64 block inside the 128 x 128 tile
+    const int64_t c0 = (int64_t)blockIdx.z * chunk;
+    const int64_t c1 = min(c0 + chunk, N);
+    g_f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (g_f32x4){0.f, 0.f, 0.f, 0.f};
+    float pb[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t m0 = c0; m0 < c1; m0 += 16) {                         // c0 < N for every block of the grid
+        const int64_t m = m0 + 4 * kq;
+        __syncthreads();                                               // previous step's panel reads are done
+        // this wave stages rows / columns [32w, 32w + 32) of both panels: lane (i, kq) handles rows 32w + i and 32w + 16 + i
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int rr = 32 * w + 16 * h + i;
+            g_f32x4 st[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) st[c] = *reinterpret_cast<const g_f32x4*>(Sprev + ((int64_t)c * K + k0 + rr) * ld + m);
+            g_f32x4 av[C];
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                float zk[D > 0 ? D : 1], zkk[E > 0 ? E : 1], a1[C];
+#pragma unroll
+                for (int j = 0; j < D; ++j) zk[j] = st[1 + j][s2];
+#pragma unroll
+                for (int j = 0; j < E; ++j) zkk[j] = st[1 + D + j][s2];
+                act_from_stored<D, E>(st[0][s2], zk, zkk, nd.shift, a1);
+#pragma unroll
+                for (int c = 0; c < C; ++c) av[c][s2] = a1[c];
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                *reinterpret_cast<g_f32x4*>(&PA[c][rr][4 * kq]) = av[c];
+                g_f32x4 z = *reinterpret_cast<const g_f32x4*>(Zb + ((int64_t)c * Ho + n0 + rr) * ld + m);
+                if (m + 3 >= c1) {
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2) if (m + s2 >= c1) z[s2] = 0.f;
+                }
+                *reinterpret_cast<g_f32x4*>(&PZ[c][rr][4 * kq]) = z;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            g_f32x4 za[4], ab[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                za[t] = *reinterpret_cast<const g_f32x4*>(&PZ[c][wn + 16 * t + i][4 * kq]);
+                ab[t] = *reinterpret_cast<const g_f32x4*>(&PA[c][wk + 16 * t + i][4 * kq]);
+            }
+            if (c == 0 && wk == 0) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) pb[nt] += (za[nt][0] + za[nt][1]) + (za[nt][2] + za[nt][3]);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+                        acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[nt][s2], ab[kt][s2], acc[nt][kt], 0, 0, 0);
+        }
+    }
+    float* gW = grad + nd.offW[lin];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                atomicAdd(&gW[(int64_t)(n0 + wn + 16 * nt + 4 * kq + r) * K + k0 + wk + 16 * kt + i], acc[nt][kt][r]);
+    if (blockIdx.y == 0 && wk == 0) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            float v = pb[nt];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (kq == 0) atomicAdd(&grad[nd.offB[lin] + n0 + wn + 16 * nt + i], v);
+        }
+    }
+}
