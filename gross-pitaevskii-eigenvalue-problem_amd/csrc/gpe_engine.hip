@@ -579,7 +579,11 @@ static int mlp_forward(gpe_engine* e, Batch& b, bool store) {
         for (int lin = 0; lin < nd.n_lin; ++lin) {
             const float* Sprev = lin > 0 ? b.S[lin - 1] : nullptr;
             float* Out = (lin == nd.n_lin - 1) ? b.O : b.S[lin];
-            if (lin > 0 && nd.width[lin] % 64 == 0 && nd.width[lin + 1] % 64 == 0 && e->gen_mfma) {   // wide map: matrix cores
+            if (lin > 0 && nd.width[lin] % 64 == 0 && nd.width[lin + 1] % 256 == 0 && e->gen_mfma && e->gen_mfma2) {
+                dim3 grid(cdiv(b.n, 16), nd.width[lin + 1] / 256);      // a block = one point tile x 256 outputs, jets shared through LDS
+                DISPATCH_FWD(b, hipLaunchKernelGGL((g_fwd_layer_mfma2<CC, EE>), grid, dim3(256), 0, e->stream, nd, lin, e->theta,
+                                                    Sprev, Out, b.n, b.ld));
+            } else if (lin > 0 && nd.width[lin] % 64 == 0 && nd.width[lin + 1] % 64 == 0 && e->gen_mfma) {   // wide map: matrix cores
                 dim3 grid(cdiv(cdiv(b.n, 16), 4), nd.width[lin + 1] / 64);
                 DISPATCH_FWD(b, hipLaunchKernelGGL((g_fwd_layer_mfma<CC, EE>), grid, dim3(256), 0, e->stream, nd, lin, e->theta,
                                                     Sprev, Out, b.n, b.ld));

@@ -518,3 +518,78 @@ __global__ __launch_bounds__(256, 1) void g_bwd_weight_mfma2(NetDesc nd, int lin
         }
     }
 }
+
+// Block-cooperative forward map: the 4 waves of a block take the SAME 16-point tile and 4 consecutive 64-feature output blocks;
+// the activation jets of the tile (B operand) are recomputed once per block, 64 input features at a time, into an LDS panel
+// [channel][point][64 k] (a lane reads its 4 consecutive k as one ds_read_b128).  grid (ceil(N/16), Ho/256), block 256.
+// Needs Ho % 256 == 0, K % 64 == 0, lin >= 1.
+template <int C, int E>
+__global__ __launch_bounds__(256) void g_fwd_layer_mfma2(NetDesc nd, int lin, const float* __restrict__ theta,
+                                                         const float* __restrict__ Sprev, float* __restrict__ Out, int64_t N,
+                                                         int64_t ld) {
+    constexpr int D = C - 1 - E;
+    __shared__ __attribute__((aligned(16))) float PB[C][16][68];       // +4 pad: rows of different points start in different banks
+    const int K = nd.width[lin], Ho = nd.width[lin + 1];
+    const int lane = threadIdx.x & 63, i = lane & 15, kq = lane >> 4, w = threadIdx.x >> 6;
+    const int64_t m0 = (int64_t)blockIdx.x * 16;
+    const int n0 = blockIdx.y * 256 + 64 * w;
+    const float* W = theta + nd.offW[lin];
+    const float* bias = theta + nd.offB[lin];
+    const int64_t mp = m0 + i;
+    g_f32x4 acc[4][C];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        acc[nt][0] = *reinterpret_cast<const g_f32x4*>(&bias[n0 + 16 * nt + 4 * kq]);
+#pragma unroll
+        for (int c = 1; c < C; ++c) acc[nt][c] = (g_f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    for (int kb = 0; kb < K; kb += 64) {
+        __syncthreads();
+        // wave w recomputes the jets of input features kb + 16w .. kb + 16w + 15 at the 16 points: lane (point i, kq) -> 4 features
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            const int kl = 16 * w + 4 * kq + s2, k = kb + kl;
+            float zk[D > 0 ? D : 1], zkk[E > 0 ? E : 1], a[C];
+            const float t = Sprev[((int64_t)0 * K + k) * ld + mp];
+#pragma unroll
+            for (int j = 0; j < D; ++j) zk[j] = Sprev[((int64_t)(1 + j) * K + k) * ld + mp];
+#pragma unroll
+            for (int j = 0; j < E; ++j) zkk[j] = Sprev[((int64_t)(1 + D + j) * K + k) * ld + mp];
+            act_from_stored<D, E>(t, zk, zkk, nd.shift, a);
+#pragma unroll
+            for (int c = 0; c < C; ++c) PB[c][i][kl] = a[c];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k0 = 0; k0 < 64; k0 += 16) {
+            g_f32x4 wv[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                wv[nt] = *reinterpret_cast<const g_f32x4*>(&W[(int64_t)(n0 + 16 * nt + i) * K + kb + k0 + 4 * kq]);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const g_f32x4 bv = *reinterpret_cast<const g_f32x4*>(&PB[c][i][k0 + 4 * kq]);
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc[nt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nt][s2], bv[s2], acc[nt][c], 0, 0, 0);
+            }
+        }
+    }
+    const bool last = (lin == nd.n_lin - 1);
+    if (mp < N) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + 16 * nt + 4 * kq + r;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    float v = acc[nt][c][r];
+                    if (c == 0 && !last) v = gpe_tanh(v);
+                    Out[((int64_t)c * Ho + n) * ld + mp] = v;
+                }
+            }
+    }
+}
