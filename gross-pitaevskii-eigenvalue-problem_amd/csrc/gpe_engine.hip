@@ -695,7 +695,11 @@ static int mlp_backward(gpe_engine* e, Batch& b, bool close = false, bool assign
                                                     Zb, e->grad, b.n, b.ld));
             }
             if (lin > 0) {
-                if (K % 64 == 0 && Ho % 16 == 0 && e->gen_mfma) {
+                if (K % 256 == 0 && Ho % 64 == 0 && e->gen_mfma && e->gen_mfma2) {
+                    dim3 gd(cdiv(b.n, 16), K / 256);
+                    DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_data_mfma2<CC>), gd, dim3(256), 0, e->stream, nd, lin, e->theta, Zb,
+                                                        nxt, b.n, b.ld));
+                } else if (K % 64 == 0 && Ho % 16 == 0 && e->gen_mfma) {
                     dim3 gd(cdiv(cdiv(b.n, 16), 4), K / 64);
                     DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_data_mfma<CC>), gd, dim3(256), 0, e->stream, nd, lin, e->theta, Zb,
                                                         nxt, b.n, b.ld));

@@ -593,3 +593,61 @@ __global__ __launch_bounds__(256) void g_fwd_layer_mfma2(NetDesc nd, int lin, co
             }
     }
 }
+
+// Block-cooperative adjoint map: 4 waves = the same 16-point tile x 4 consecutive 64-feature blocks of the INPUT side; the adjoint
+// jets Zb of the tile (B operand) are staged once per block, 64 output features at a time, in an LDS panel [channel][point][64 n].
+// grid (ceil(N/16), K/256), block 256.  Needs K % 256 == 0, Ho % 64 == 0.
+template <int C>
+__global__ __launch_bounds__(256) void g_bwd_data_mfma2(NetDesc nd, int lin, const float* __restrict__ theta,
+                                                        const float* __restrict__ Zb, float* __restrict__ Aprev, int64_t N,
+                                                        int64_t ld) {
+    __shared__ __attribute__((aligned(16))) float PB[C][16][68];
+    const int K = nd.width[lin], Ho = nd.width[lin + 1];
+    const int lane = threadIdx.x & 63, i = lane & 15, kq = lane >> 4, w = threadIdx.x >> 6;
+    const int64_t m0 = (int64_t)blockIdx.x * 16;
+    const int k0 = blockIdx.y * 256 + 64 * w;
+    const float* W = theta + nd.offW[lin];
+    const int64_t mp = m0 + i;
+    g_f32x4 acc[4][C];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[kt][c] = (g_f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nb = 0; nb < Ho; nb += 64) {
+        __syncthreads();
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            const int nl = 16 * w + 4 * kq + s2;
+#pragma unroll
+            for (int c = 0; c < C; ++c) PB[c][i][nl] = Zb[((int64_t)c * Ho + nb + nl) * ld + mp];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int n0 = 0; n0 < 64; n0 += 16) {
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                const int n = nb + n0 + 4 * kq + s2;
+                float wv[4];
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) wv[kt] = W[(int64_t)n * K + k0 + 16 * kt + i];
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float z = PB[c][i][n0 + 4 * kq + s2];
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+                        acc[kt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[kt], z, acc[kt][c], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (mp < N) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = k0 + 16 * kt + 4 * kq + r;
+#pragma unroll
+                for (int c = 0; c < C; ++c) Aprev[((int64_t)c * K + k) * ld + mp] = acc[kt][c][r];
+            }
+    }
+}
