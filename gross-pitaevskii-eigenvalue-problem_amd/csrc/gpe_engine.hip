@@ -695,10 +695,12 @@ static int mlp_backward(gpe_engine* e, Batch& b, bool close = false, bool assign
                                                     Zb, e->grad, b.n, b.ld));
             }
             if (lin > 0) {
+                bool act_done = false;
                 if (K % 256 == 0 && Ho % 64 == 0 && e->gen_mfma && e->gen_mfma2) {
-                    dim3 gd(cdiv(b.n, 16), K / 256);
-                    DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_data_mfma2<CC>), gd, dim3(256), 0, e->stream, nd, lin, e->theta, Zb,
-                                                        nxt, b.n, b.ld));
+                    dim3 gd(cdiv(b.n, 16), K / 256);             // activation adjoint of layer lin-1 fused into the epilogue
+                    DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_data_mfma2<CC, EE>), gd, dim3(256), 0, e->stream, nd, lin, e->theta, Zb,
+                                                        nxt, Sprev, b.n, b.ld));
+                    act_done = true;
                 } else if (K % 64 == 0 && Ho % 16 == 0 && e->gen_mfma) {
                     dim3 gd(cdiv(cdiv(b.n, 16), 4), K / 64);
                     DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_data_mfma<CC>), gd, dim3(256), 0, e->stream, nd, lin, e->theta, Zb,
@@ -712,8 +714,10 @@ static int mlp_backward(gpe_engine* e, Batch& b, bool close = false, bool assign
                     DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_data<CC, G_FB>), gd, dim3(256), 0, e->stream, nd, lin, e->theta, Zb,
                                                         nxt, b.n, b.ld));
                 }
-                dim3 ga(cdiv(b.n, 256), K);
-                DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_act<CC, EE>), ga, dim3(256), 0, e->stream, K, Sprev, nxt, b.n, b.ld));
+                if (!act_done) {
+                    dim3 ga(cdiv(b.n, 256), K);
+                    DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_act<CC, EE>), ga, dim3(256), 0, e->stream, K, Sprev, nxt, b.n, b.ld));
+                }
                 Zb = nxt;
                 nxt = (nxt == b.A0) ? b.A1 : b.A0;
             }

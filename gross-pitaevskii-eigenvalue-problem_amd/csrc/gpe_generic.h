@@ -597,10 +597,13 @@ __global__ __launch_bounds__(256) void g_fwd_layer_mfma2(NetDesc nd, int lin, co
 // Block-cooperative adjoint map: 4 waves = the same 16-point tile x 4 consecutive 64-feature blocks of the INPUT side; the adjoint
 // jets Zb of the tile (B operand) are staged once per block, 64 output features at a time, in an LDS panel [channel][point][64 n].
 // grid (ceil(N/16), K/256), block 256.  Needs K % 256 == 0, Ho % 64 == 0.
-template <int C>
+// Sact != NULL: the stored (t, z_k, z_L) of the layer the adjoint lands on -- the activation adjoint (g_bwd_act) is applied in the
+// epilogue, all channels of a (feature, point) pair being in one lane, so that pass and its round trip through HBM disappear.
+template <int C, int E>
 __global__ __launch_bounds__(256) void g_bwd_data_mfma2(NetDesc nd, int lin, const float* __restrict__ theta,
-                                                        const float* __restrict__ Zb, float* __restrict__ Aprev, int64_t N,
-                                                        int64_t ld) {
+                                                        const float* __restrict__ Zb, float* __restrict__ Aprev,
+                                                        const float* __restrict__ Sact, int64_t N, int64_t ld) {
+    constexpr int D = C - 1 - E;
     __shared__ __attribute__((aligned(16))) float PB[C][16][68];
     const int K = nd.width[lin], Ho = nd.width[lin + 1];
     const int lane = threadIdx.x & 63, i = lane & 15, kq = lane >> 4, w = threadIdx.x >> 6;
@@ -646,8 +649,23 @@ __global__ __launch_bounds__(256) void g_bwd_data_mfma2(NetDesc nd, int lin, con
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int k = k0 + 16 * kt + 4 * kq + r;
+                float ab[C], zv[C];
 #pragma unroll
-                for (int c = 0; c < C; ++c) Aprev[((int64_t)c * K + k) * ld + mp] = acc[kt][c][r];
+                for (int c = 0; c < C; ++c) ab[c] = acc[kt][c][r];
+                if (Sact) {
+                    float zk[D > 0 ? D : 1], zkk[E > 0 ? E : 1];
+                    const float t = Sact[((int64_t)0 * K + k) * ld + mp];
+#pragma unroll
+                    for (int j = 0; j < D; ++j) zk[j] = Sact[((int64_t)(1 + j) * K + k) * ld + mp];
+#pragma unroll
+                    for (int j = 0; j < E; ++j) zkk[j] = Sact[((int64_t)(1 + D + j) * K + k) * ld + mp];
+                    act_adjoint<D, E>(t, zk, zkk, ab, zv);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) zv[c] = ab[c];
+                }
+#pragma unroll
+                for (int c = 0; c < C; ++c) Aprev[((int64_t)c * K + k) * ld + mp] = zv[c];
             }
     }
 }
