@@ -1,22 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the GPE eigenvalue-residual training step on MI355X.
 
-A "step" is one full pass of the hot path over the collocation batch: jet forward (psi, grad psi, diag Hessian),
+A "step" is one full pass of the hot path over the collocation batch: jet forward (psi, grad psi, Laplacian),
 Rayleigh quotient mu, residual, boundary + normalisation penalties, reverse pass, grad-norm clip, Adam, scheduler.
 
 Workload (config.workload = "ns_2d_4x64"): BASELINE.json's north-star configuration -- the one its metric target is
 quoted on -- 2D isotropic harmonic trap, g = 500, MLP [2,64,64,64,64,1] (4 hidden x 64), 1 048 576 collocation points
 per GPU (1024 x 1024 uniform grid per rank), 512 boundary points; synthetic seeded weights (reference init a13).
-With --gpus N every rank owns its own 1 048 576-point shard (weak scaling); the two per-step exchanges
-(8 doubles, then P+4 floats) are RCCL all-reduces through torch.distributed.
+
+--gpus N (N > 1): when RANK is not in the environment this process is only a launcher -- it starts N fresh worker processes
+(one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) BEFORE anything touches the GPU and relays their exit codes;
+under torchrun (RANK set) it is a worker.  Workers shard the points and exchange through the ENGINE's own RCCL communicator
+(gpe_comm_init / gpe_step_dp: two all-reduces per step on a dedicated HIP stream, no Python between the phases);
+torch.distributed is used for the rendezvous of the ncclUniqueId, the barriers and the max-over-ranks of the time.
+--scaling weak (default): every rank owns a full per-GPU grid.  --scaling strong: BASELINE's global size is split over ranks.
 
 Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
-  roofline      -- dominant kernel (fused jet reverse pass) algorithmic FLOP / HIP-event time vs the fp32 MFMA peak
-  cpu_baseline  -- the reference's op sequence (torch-autograd restatement, oracle/torch_ref.py) timed on this host
+  roofline      -- dominant kernel (jet reverse pass) algorithmic FLOP / HIP-event time vs the fp32 MFMA peak
+  cpu_baseline  -- the reference's op sequence (torch-autograd restatement, oracle/torch_ref.py) and the native C++/OpenMP
+                   jet restatement (oracle/cpu_ref) timed on this host
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -28,18 +35,21 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
 
 WORKLOADS = {
-    # name: (layers, dim, points per GPU (grid), gamma, domain half-width)
-    "ns_2d_4x64": dict(layers=[2, 64, 64, 64, 64, 1], grid=(1024, 1024), gamma=500.0, half=8.0),
-    "cfg2_1d_4x64": dict(layers=[1, 64, 64, 64, 64, 1], grid=(65536,), gamma=100.0, half=10.0),
-    "cfg3_2d_5x128": dict(layers=[2, 128, 128, 128, 128, 128, 1], grid=(512, 256), gamma=500.0, half=8.0),
+    # name: layers, per-GPU grid (weak scaling), global grid of the BASELINE config (strong scaling), gamma, domain half-width
+    "ns_2d_4x64": dict(layers=[2, 64, 64, 64, 64, 1], grid=(1024, 1024), global_grid=(1024, 1024), gamma=500.0, half=8.0),
+    "cfg1_1d_4x32": dict(layers=[1, 32, 32, 32, 32, 1], grid=(2048,), global_grid=(2048,), gamma=0.0, half=10.0),
+    "cfg2_1d_4x64": dict(layers=[1, 64, 64, 64, 64, 1], grid=(65536,), global_grid=(65536,), gamma=100.0, half=10.0),
+    # BASELINE configs[2]: 1 048 576 points over 8 GPUs = 131 072 per GPU
+    "cfg3_2d_5x128": dict(layers=[2, 128, 128, 128, 128, 128, 1], grid=(512, 256), global_grid=(1024, 1024), gamma=500.0, half=8.0),
     # BASELINE configs[3]: rotating trap, complex psi (n_out = 2), 6x128; 2 097 152 points over 8 GPUs = 262 144 per GPU
-    "cfg4_2d_6x128_rot": dict(layers=[2, 128, 128, 128, 128, 128, 128, 2], grid=(512, 512), gamma=500.0, half=8.0,
-                              complex_psi=True, omega_rot=0.8),
-    # BASELINE configs[4] shape: 3D anisotropic trap, 6x256 (generic layer-materialised kernel set; no fused path for H = 256 yet).
-    # 4 194 304 points over 8 GPUs = 524 288 per GPU; the grid here is a quarter of that to keep the default run short.
-    "cfg5_3d_6x256": dict(layers=[3, 256, 256, 256, 256, 256, 256, 1], grid=(64, 64, 32), gamma=1000.0, half=6.0, generic_ok=True),
+    "cfg4_2d_6x128_rot": dict(layers=[2, 128, 128, 128, 128, 128, 128, 2], grid=(512, 512), global_grid=(2048, 1024), gamma=500.0,
+                              half=8.0, complex_psi=True, omega_rot=0.8),
+    # BASELINE configs[4]: 3D anisotropic trap omega = (1, 1.4, 2), g = 1000, 6x256; 4 194 304 points over 8 GPUs = 524 288 per GPU
+    "cfg5_3d_6x256": dict(layers=[3, 256, 256, 256, 256, 256, 256, 1], grid=(64, 128, 64), global_grid=(256, 128, 128), gamma=1000.0,
+                          half=6.0, omega=(1.0, 1.4, 2.0), generic_ok=True),
 }
 
 
@@ -55,36 +65,50 @@ def reference_init(layers, seed=0, mode=0):
     return torch.cat(flat).numpy().astype(np.float32)
 
 
-def make_points(wl, rank, world):
+def make_points(wl, rank, world, scaling="weak"):
+    """Shard `rank` of the point grid: contiguous block along the first axis (grid order keeps the quadrature additive).
+    weak: the global grid is `world` per-GPU grids side by side; strong: the BASELINE global grid cut into `world` blocks."""
     half = wl["half"]
-    if len(wl["grid"]) == 1:
-        n = wl["grid"][0]
-        xs = np.linspace(-half, half, n * world, dtype=np.float64)
-        x = xs[rank * n:(rank + 1) * n].reshape(-1, 1)
-        dx = 2 * half / (n * world - 1)
+    if scaling == "strong":
+        g = tuple(wl["global_grid"])
+        if g[0] % world:
+            raise SystemExit(f"strong scaling: first grid axis {g[0]} is not divisible by {world} ranks")
+        n0, n0_glob = g[0] // world, g[0]
+    else:
+        g = tuple(wl["grid"])
+        n0, n0_glob = g[0], g[0] * world
+    x0 = np.linspace(-half, half, n0_glob, dtype=np.float64)
+    h0 = 2 * half / (n0_glob - 1)
+    xs = x0[rank * n0:(rank + 1) * n0]
+    if len(g) == 1:
+        x = xs.reshape(-1, 1)
+        dx = h0
         xb = np.array([[-half], [half]])
-    elif len(wl["grid"]) == 3:
-        nx, ny, nz = wl["grid"]
-        xs = np.linspace(-half, half, nx * world, dtype=np.float64)[rank * nx:(rank + 1) * nx]
-        ys = np.linspace(-half, half, ny, dtype=np.float64)
-        zs = np.linspace(-half, half, nz, dtype=np.float64)
+    elif len(g) == 3:
+        ys = np.linspace(-half, half, g[1], dtype=np.float64)
+        zs = np.linspace(-half, half, g[2], dtype=np.float64)
         X, Y, Z = np.meshgrid(xs, ys, zs, indexing="ij")
         x = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
-        dx = (2 * half / (nx * world - 1)) * (2 * half / (ny - 1)) * (2 * half / (nz - 1))
+        dx = h0 * (2 * half / (g[1] - 1)) * (2 * half / (g[2] - 1))
         t = np.linspace(-half, half, 23, endpoint=False)
         A, B = np.meshgrid(t, t, indexing="ij")
         xb = np.stack([A.ravel(), B.ravel(), np.full(A.size, half)], axis=1)          # one face of the box, 529 points
     else:
-        nx, ny = wl["grid"]
-        xs = np.linspace(-half, half, nx * world, dtype=np.float64)[rank * nx:(rank + 1) * nx]
-        ys = np.linspace(-half, half, ny, dtype=np.float64)
+        ys = np.linspace(-half, half, g[1], dtype=np.float64)
         X, Y = np.meshgrid(xs, ys, indexing="ij")
         x = np.stack([X.ravel(), Y.ravel()], axis=1)
-        dx = (2 * half / (nx * world - 1)) * (2 * half / (ny - 1))
+        dx = h0 * (2 * half / (g[1] - 1))
         t = np.linspace(-half, half, 128, endpoint=False)
         xb = np.concatenate([np.stack([t, np.full_like(t, -half)], 1), np.stack([np.full_like(t, half), t], 1),
                              np.stack([-t, np.full_like(t, half)], 1), np.stack([np.full_like(t, -half), -t], 1)])
     return x.astype(np.float32), float(dx), xb.astype(np.float32)
+
+
+def oracle_problem(wl, dx):
+    from oracle import gpe_oracle as go
+    return go.Problem(layers=wl["layers"], gamma=wl["gamma"], p=3, kinetic_coeff=0.5, pot_scale=0.5, dx=dx,
+                      w_bc=10.0, w_norm=20.0, complex_psi=bool(wl.get("complex_psi", False)),
+                      omega_rot=float(wl.get("omega_rot", 0.0)), omega=tuple(wl.get("omega", (1.0, 1.0, 1.0))))
 
 
 def cpu_baseline(wl, flat, budget_s=12.0, n_sample=8192):
@@ -94,9 +118,7 @@ def cpu_baseline(wl, flat, budget_s=12.0, n_sample=8192):
     x, dx, xb = make_points(wl, 0, 1)
     idx = np.linspace(0, x.shape[0] - 1, n_sample).astype(np.int64)
     xs = x[idx]
-    pb = go.Problem(layers=wl["layers"], gamma=wl["gamma"], p=3, kinetic_coeff=0.5, pot_scale=0.5, dx=dx,
-                    w_bc=10.0, w_norm=20.0, complex_psi=bool(wl.get("complex_psi", False)),
-                    omega_rot=float(wl.get("omega_rot", 0.0)))
+    pb = oracle_problem(wl, dx)
     trn = tr.TorchTrainer(pb, flat, xs, xb, lr=1e-3, sched=go.SCHED_CONST)
     ncpu = os.cpu_count() or 1
     best = None
@@ -122,20 +144,83 @@ def cpu_baseline(wl, flat, budget_s=12.0, n_sample=8192):
                        f"thread sweep {sweep}")
 
 
+def cpu_baseline_native(wl, flat, budget_s=10.0, n_sample=32768):
+    """The like-for-like algorithm on the host: oracle/cpu_ref (C++/OpenMP forward-mode jets + hand-derived reverse pass, fp32),
+    thread sweep {1, all cores}.  Checker-side code (oracle/): timed here, never shipped."""
+    try:
+        from oracle import cpu_ref
+        lib = cpu_ref.load()
+    except Exception as ex:                                  # not built on this host: report, do not fail the bench
+        return dict(value=None, kind="native", error=str(ex)[:200])
+    x, dx, xb = make_points(wl, 0, 1)
+    idx = np.linspace(0, x.shape[0] - 1, n_sample).astype(np.int64)
+    xs = np.ascontiguousarray(x[idx])
+    pb = oracle_problem(wl, dx)
+    ncpu = os.cpu_count() or 1
+    out = {}
+    for nt in sorted({1, ncpu}):
+        cpu_ref.step(lib, pb, flat, xs, threads=nt)           # warm-up
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            cpu_ref.step(lib, pb, flat, xs, threads=nt)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s / 2 or n >= 400:
+                break
+        out[nt] = n * n_sample / el
+    best_nt = max(out, key=out.get)
+    return dict(value=out[best_nt], unit="points/s", cores=int(best_nt), kind="native", host_cpus=int(ncpu),
+                per_threads={str(k): v for k, v in out.items()},
+                sample=f"forward jets + residual + reverse pass (loss and gradient, no Adam) of oracle/cpu_ref (C++/OpenMP, fp32) "
+                       f"on a {n_sample}-point slice of the same workload; thread sweep {sorted(out)}")
+
+
+def launch_workers(args):
+    """--gpus N without RANK in the environment: start N fresh worker processes.  Nothing here touches the GPU
+    (a process that has initialised HIP must not be replaced or forked on this pool)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rcs = [p.wait() for p in procs]
+    sys.exit(max(abs(rc) for rc in rcs))
+
+
+def load_profile_json(name):
+    p = os.path.join(PROFILE_DIR, name)
+    if os.path.exists(p):
+        try:
+            return json.load(open(p)), os.path.relpath(p, ROOT)
+        except Exception:
+            pass
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="ns_2d_4x64", choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--exchange", default="engine", choices=["engine", "torch"],
+                    help="N > 1: all-reduces issued by the engine (native RCCL) or by torch.distributed between the phases")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        launch_workers(args)                               # does not return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or "RANK" in os.environ          # under torchrun always take the RCCL path, even at world 1
@@ -143,15 +228,17 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        world = dist.get_world_size()
 
     import gpe_pinn
     wl = WORKLOADS[args.workload]
     layers = wl["layers"]
     flat = reference_init(layers, seed=0)
-    x, dx, xb = make_points(wl, rank, world)
+    x, dx, xb = make_points(wl, rank, world, args.scaling)
     n_local = x.shape[0]
     cfg = gpe_pinn.GPEConfig(layers=layers, gamma=wl["gamma"], p=3, kinetic_coeff=0.5, pot_scale=0.5, dx=dx,
                              w_bc=10.0, w_norm=20.0, lr=1e-3, n_global=n_local * world, world_size=world,
+                             omega=tuple(wl.get("omega", (1.0, 1.0, 1.0))),
                              complex_psi=bool(wl.get("complex_psi", False)), omega_rot=float(wl.get("omega_rot", 0.0)))
     eng = gpe_pinn.Engine(cfg, device=local_rank)
     fused = eng.active_path == gpe_pinn.PATH_FUSED
@@ -160,17 +247,23 @@ def main():
     eng.set_params(flat)
     eng.bind_points(torch.as_tensor(x, device=f"cuda:{local_rank}"))      # inputs resident in HBM before timing
     eng.bind_boundary(torch.as_tensor(xb, device=f"cuda:{local_rank}"))
+    kernels = eng.active_kernels
+    native = use_dist and args.exchange == "engine"
+    if native:
+        eng.comm_init(rank, world)
 
     def run_steps(k):
         if not use_dist:
             eng.run(k)
+        elif native:
+            eng.run_dp(k)
         else:
             for _ in range(k):
                 eng.step_distributed()
 
     run_steps(args.warmup)
     eng.synchronize()
-    eng.profile_enable(True)
+    eng.profile_enable(True)           # HIP events around the two dominant kernels, on the engine's stream, over the timed region
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -187,6 +280,7 @@ def main():
     prof = eng.profile_read()
     eng.profile_enable(False)
     sc = eng.read_scalars()
+    comm = eng.comm_info()
 
     if rank == 0:
         flops_pt, bmat_pt = eng.step_cost()
@@ -195,43 +289,53 @@ def main():
         # its per-point figure is reported next to the executed one -- the roofline fraction uses only executed flops)
         d_in, Hh, Lh = layers[0], layers[1], len(layers) - 2
         chan = d_in + 2
+        gemm_fwd = 2.0 * d_in * Hh + chan * (2.0 * Hh * Hh * (Lh - 1) + 2.0 * Hh * layers[-1])
         survey_fwd = 2.0 * d_in * Hh + (1 + 2 * d_in) * (2.0 * Hh * Hh * (Lh - 1) + 2.0 * Hh * layers[-1]) + Hh * Lh * (3 + 5 * d_in)
         pts = n_local * world * args.steps
         value = pts / elapsed
+        n_rows = n_local + (int(xb.shape[0]) if xb.shape[0] * 8 <= n_local else 0)     # merged boundary rows ride in the launch
         bwd_s = prof["bwd_ms"] / max(1, prof["bwd_launches"]) * 1e-3
         fwd_s = prof["fwd_ms"] / max(1, prof["fwd_launches"]) * 1e-3
-        ach = 2.0 * f_fwd * n_local / bwd_s / 1e12 if bwd_s > 0 else 0.0
-        ach_f = f_fwd * n_local / fwd_s / 1e12 if fwd_s > 0 else 0.0
-        # HBM bytes per launch of the dominant kernel from the committed PMC run of this same workload
-        # (profiles/r01/traffic_ns_v7.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 1/2-fetch correction applied)
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01", "traffic_ns_v7.json")
-        if args.workload == "ns_2d_4x64" and os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                for k, v in tj["kernels"].items():          # the collocation batch's launch is the largest f_backward* entry
-                    if "f_backward" in k and (traffic is None or v["hbm_bytes_per_point"] * n_local > traffic):
-                        traffic = v["hbm_bytes_per_point"] * n_local
-                        traffic_src = "profiles/r01/traffic_ns_v7.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-            except Exception:
-                pass
+        ach = 2.0 * f_fwd * n_rows / bwd_s / 1e12 if bwd_s > 0 else 0.0
+        ach_gemm = 2.0 * gemm_fwd * n_rows / bwd_s / 1e12 if bwd_s > 0 else 0.0
+        ach_f = f_fwd * n_rows / fwd_s / 1e12 if fwd_s > 0 else 0.0
+        # HBM bytes per launch of the dominant kernel and the SQ counter shares: from the committed rocprofv3 --pmc passes of
+        # this same command (tools/profile_round.sh); never measured in this process -> always labelled "from_profile"
+        traffic, traffic_src, util = None, None, None
+        tj, tsrc = load_profile_json(f"traffic_{args.workload}.json")
+        if tj:
+            for k, v in tj.get("kernels", {}).items():
+                if ("f_backward" in k or "bwd" in k) and (traffic is None or v["hbm_bytes_per_point"] * n_rows > traffic):
+                    traffic = v["hbm_bytes_per_point"] * n_rows
+                    traffic_src = f"from_profile: {tsrc} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 1/2-fetch correction)"
+        uj, usrc = load_profile_json(f"mfma_util_{args.workload}.json")
+        if uj:
+            util = dict(uj, source=f"from_profile: {usrc}")
+        aj, asrc = load_profile_json(f"accuracy_{args.workload}.json")
         out = {
             "metric": "collocation-point residual evals/sec (full training step: jets fwd + residual + reverse + Adam)",
             "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "layers": layers, "points_per_gpu": n_local,
                        "global_points": n_local * world, "gamma": wl["gamma"], "boundary_points": int(xb.shape[0]),
-                       "parallelism": f"dp{world}", "kernel_path": "fused_mfma_f32_16x16x4" if fused else "generic_valu_layerwise"},
+                       "parallelism": f"dp{world}", "kernel_path": "fused_mfma_f32_16x16x4" if fused else "generic_layerwise_mfma",
+                       "exchange": ("engine_rccl" if native else "torch_distributed") if use_dist else "none"},
             "per_gpu_points_per_s": value / world,
-            "final_loss": sc["loss"], "final_mu": sc["mu"],
-            "roofline": {"bound": "mfma", "kernel": "%s<%d,%d,...> (fused jet reverse pass, %d channels)" % ("f_backward_coop" if ((layers[1] <= 64 and len(layers) - 3 <= 3) or (layers[1] == 128 and len(layers) - 3 <= 5 and layers[0] <= 2)) else "f_backward", layers[1], chan, chan),
+            "rccl_ranks": comm["world"] if native else (world if use_dist else 0),
+            "collectives_per_step": (comm["collectives"] / max(1, args.steps + args.warmup)) if native else (2 if use_dist else 0),
+            "final_loss": sc["loss"], "mu_after_timed_steps": sc["mu"],
+            "mu_abs_err": (aj or {}).get("mu_abs_err"), "mu_ref": (aj or {}).get("mu_ref"),
+            "mu_abs_err_source": f"from_profile: {asrc} (converged run of tools/accuracy_nd.py vs oracle/gp_ground_state_nd.py)" if aj else None,
+            "roofline": {"bound": "mfma", "kernel": kernels["bwd"],
                          "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
-                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": (bmat_pt / 2.0 * (len(layers) - 3) / (len(layers) - 2) + 4.0 * chan + 4.0 * layers[0] + 8.0) * n_local,
-                         "algorithmic_flop_per_point": 2.0 * f_fwd, "avg_launch_ms": bwd_s * 1e3,
-                         "launches": prof["bwd_launches"]},
-            "roofline_forward": {"bound": "mfma", "kernel": "f_forward<%d,%d,1>" % (layers[1], chan), "achieved": ach_f,
+                         "frac": ach / FP32_MFMA_PEAK_TFLOPS, "frac_gemm_only": ach_gemm / FP32_MFMA_PEAK_TFLOPS,
+                         "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": (bmat_pt / 2.0 * (Lh - 1) / Lh + 4.0 * chan * layers[-1] + 4.0 * d_in) * n_rows,
+                         "algorithmic_flop_per_point": 2.0 * f_fwd, "gemm_flop_per_point": 2.0 * gemm_fwd,
+                         "rows_per_launch": n_rows, "avg_launch_ms": bwd_s * 1e3, "launches": prof["bwd_launches"],
+                         "counters": util},
+            "roofline_forward": {"bound": "mfma", "kernel": kernels["fwd"], "achieved": ach_f,
                                  "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_f / FP32_MFMA_PEAK_TFLOPS,
                                  "algorithmic_flop_per_point": f_fwd, "avg_launch_ms": fwd_s * 1e3},
             "jet_channels": chan, "survey_8d_step_flop_per_point": 3.0 * survey_fwd,
@@ -240,15 +344,17 @@ def main():
         }
         if not fused:       # layer-wise generic set (MFMA maps for wide layers): no per-kernel events, the whole step is rated
             tf = flops_pt * value / world / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "generic layer-wise set (g_*_mfma maps + VALU head/activation kernels), whole step",
+            out["roofline"] = {"bound": "mfma", "kernel": "generic layer-wise set (%s, %s + head/activation kernels), whole step" % (kernels["fwd"], kernels["bwd"]),
                                "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS,
                                "traffic": None, "algorithmic_flop_per_point": flops_pt, "avg_launch_ms": elapsed / args.steps * 1e3}
             out.pop("roofline_forward", None)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, flat)
+            out["cpu_baseline_native"] = cpu_baseline_native(wl, flat)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
+        eng.close()
         dist.destroy_process_group()
 
 

@@ -13,6 +13,7 @@ GPE_ABI_VERSION = 1
 GPE_MAX_LAYERS = 12
 GPE_MAX_ORTH = 4
 GPE_MAX_DIM = 3
+GPE_COMM_ID_BYTES = 128
 
 GPE_OK = 0
 GPE_ERR_INVALID, GPE_ERR_HIP, GPE_ERR_NONFINITE, GPE_ERR_STATE, GPE_ERR_NOMEM = -1, -2, -3, -4, -5
@@ -68,6 +69,13 @@ SYMBOLS = {
     "gpe_destroy": (None, [_vp]),
     "gpe_last_error": (C.c_char_p, [_vp]),
     "gpe_active_path": (_int, [_vp]),
+    "gpe_active_kernels": (_int, [_vp, C.c_char_p, C.c_size_t]),
+    "gpe_comm_unique_id": (_int, [_vp, _vp]),
+    "gpe_comm_init": (_int, [_vp, _vp, _int, _int]),
+    "gpe_comm_destroy": (_int, [_vp]),
+    "gpe_comm_info": (_int, [_vp, _P(_int), _P(_int), _P(_i64)]),
+    "gpe_step_dp": (_int, [_vp]),
+    "gpe_run_dp": (_int, [_vp, _i64]),
     "gpe_param_count": (_i64, [_vp]),
     "gpe_set_params": (_int, [_vp, _vp, C.c_size_t]),
     "gpe_get_params": (_int, [_vp, _vp, C.c_size_t]),

@@ -9,6 +9,7 @@
 //   update   : grad-norm clip, Adam, LR scheduler, history record (one single-workgroup kernel)
 // With world_size > 1 the caller all-reduces the two exchange buffers between the phases (RCCL).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -16,6 +17,8 @@
 #include <algorithm>
 #include <string>
 #include <vector>
+
+#include <rccl/rccl.h>      // types only: the library is dlopen'ed at gpe_comm_init (no link-time dependency)
 
 #include "gpe_common.h"
 #include "gpe_head.h"
@@ -257,6 +260,22 @@ struct gpe_engine {
     bool merge_bc = true;
     const float* mse_target = nullptr;
     int num_cu = 256;
+    // ---- data-parallel exchange inside the engine: RCCL on a dedicated stream (gpe_comm_init) ----
+    struct Rccl {
+        void* dl = nullptr;
+        ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+        ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+        ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+        ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+        const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    } rccl;
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_x0 = nullptr, ev_x1 = nullptr;      // compute -> exchange, exchange -> compute
+    std::vector<hipEvent_t> ev_bucket;                // one per linear map: its gradient slice is final
+    bool dp_bucket = false;                           // set by gpe_step_dp: the generic reverse pass hands finished layers to the comm stream
+    int64_t dp_collectives = 0;                       // all-reduces issued since gpe_comm_init (bench / tests)
     int phase = 0;                 // 0 idle, 1 after begin, 2 after backward
     std::string err;
     double* sums() { return dbl; }
@@ -604,6 +623,7 @@ static int mlp_forward(gpe_engine* e, Batch& b, bool store) {
 
 static int bc_join(gpe_engine* e);
 static int launch_tail(gpe_engine* e, bool add_bc);
+static int dp_allreduce_after(gpe_engine* e, void* buf, size_t count, ncclDataType_t dt, hipEvent_t ev);
 // Gradient of one batch into e->grad: assigned (first reverse pass of the step) or accumulated.  close: this is the last reverse pass of the step -- join the boundary batch's side stream, add its
 // gradient and write the exchange tail (folded into the slab reduction on the fused path)
 static int mlp_backward(gpe_engine* e, Batch& b, bool close = false, bool assign = true) {
@@ -693,6 +713,12 @@ static int mlp_backward(gpe_engine* e, Batch& b, bool close = false, bool assign
                 dim3 gw(Ho, cdiv(K, G_KB));
                 DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_weight<CC, EE, 1, G_KB>), gw, dim3(256), 0, e->stream, nd, lin, b.pts, Sprev,
                                                     Zb, e->grad, b.n, b.ld));
+            }
+            if (e->dp_bucket && close) {
+                // data-parallel step: this map's gradient slice (weights + bias, contiguous) is final -> all-reduce it on the
+                // exchange stream behind the remaining reverse pass (output map first)
+                int rcb = dp_allreduce_after(e, e->grad + nd.offW[lin], (size_t)K * Ho + Ho, ncclFloat, e->ev_bucket[lin]);
+                if (rcb) return rcb;
             }
             if (lin > 0) {
                 bool act_done = false;
@@ -796,6 +822,34 @@ const char* gpe_last_error(const gpe_engine* e) { return e ? e->err.c_str() : g_
 
 int gpe_active_path(const gpe_engine* e) { return e ? e->path : GPE_ERR_INVALID; }
 
+// names of the two dominant kernels the bound collocation batch runs (what bench.py prints as roofline.kernel, and what the
+// variant tests assert): "fwd=<...>;bwd=<...>"
+int gpe_active_kernels(gpe_engine* e, char* buf, size_t n) {
+    if (!e || !buf || n == 0) return GPE_ERR_INVALID;
+    if (e->main.n <= 0) FAIL(e, GPE_ERR_STATE, "active_kernels before bind_points");
+    const Batch& b = e->main;
+    char f[160], r[160];
+    const int maps = e->nd.n_lin - 2;
+    if (e->path == GPE_PATH_FUSED) {
+        const bool fc = fwd_coop(e, b) && (e->H <= 64 || b.C <= 4);
+        if (fc) snprintf(f, sizeof f, "f_forward_coop<%d,%d,%d,%d,%d>", e->H, b.C, b.E, e->nd.n_out, maps > 5 ? 5 : maps);
+        else snprintf(f, sizeof f, "f_forward<%d,%d,%d,%d,%s>", e->H, b.C, b.E, e->nd.n_out,
+                      (e->H <= 64 && e->fwd_wlds && staged_batch(e, b)) ? "wlds" : "l2");
+        const int kind = bwd_kind(e, b);
+        if (kind == 3) snprintf(r, sizeof r, "f_backward_coop<%d,%d,%d,%d,%d>", e->H, b.C, b.E, e->nd.n_out, maps > 5 ? 5 : maps);
+        else if (kind == 2) snprintf(r, sizeof r, "f_backward<%d,%d,%d,%d,wlds,racc%d>", e->H, b.C, b.E, e->nd.n_out, maps > 3 ? 3 : maps);
+        else snprintf(r, sizeof r, "f_backward<%d,%d,%d,%d,l2,%s>", e->H, b.C, b.E, e->nd.n_out, e->H > 64 ? "gacc" : "ldsacc");
+    } else {
+        const int W = e->nd.width[1];
+        const bool m2 = e->gen_mfma && e->gen_mfma2 && W % 256 == 0, m1 = e->gen_mfma && W % 64 == 0;
+        snprintf(f, sizeof f, "%s<%d,%d>", m2 ? "g_fwd_layer_mfma2" : (m1 ? "g_fwd_layer_mfma" : "g_fwd_layer"), b.C, b.E);
+        snprintf(r, sizeof r, "%s<%d,%d>", (e->gen_mfma && e->gen_mfma2 && W % 128 == 0) ? "g_bwd_weight_mfma2"
+                                            : (m1 ? "g_bwd_weight_mfma" : "g_bwd_weight"), b.C, b.E);
+    }
+    snprintf(buf, n, "fwd=%s;bwd=%s", f, r);
+    return GPE_OK;
+}
+
 int64_t gpe_param_count(const gpe_engine* e) { return e ? e->P : -1; }
 
 int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine** out) {
@@ -887,6 +941,8 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
             e->coop_fwd128 = !env9 || atoi(env9) != 0;
             const char* envf = getenv("GPE_COOP_FWD_MAX_TILES");
             e->coop_fwd_max_tiles = envf ? atoll(envf) : (int64_t)e->num_cu * 8;   // measured: wins below ~32 768 points, loses 8 % at 1M
+            const char* envs = getenv("GPE_STAGE_MIN_TILES");        // batches with fewer tiles take the unstaged per-wave-tile kernels
+            e->stage_min_tiles = envs ? atoll(envs) : 0;
             const char* envr = getenv("GPE_RACC");
             e->bwd_racc = (!envr || atoi(envr) != 0) && H <= 64 && (Lh - 1) >= 1 && (Lh - 1) <= 3 &&
                           ((size_t)e->Ppad + 4 * (size_t)H + 4 * (size_t)Cmain * F_TILE) * sizeof(float) + smallb + wb <= 160 * 1024;
@@ -965,12 +1021,14 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
 }
 
 static void graph_drop(gpe_engine* e);
+int gpe_comm_destroy(gpe_engine* e);
 
 void gpe_destroy(gpe_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
     if (e->side) { (void)hipStreamSynchronize(e->side); (void)hipStreamDestroy(e->side); }
+    (void)gpe_comm_destroy(e);
     graph_drop(e);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
@@ -1347,6 +1405,133 @@ int gpe_mse_loss_grad(gpe_engine* e, double* loss) {
     HIPCHK(e, hipMemcpyAsync(&sc, e->last, sizeof sc, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     if (loss) *loss = sc.loss;
+    return GPE_OK;
+}
+
+// ---- data-parallel exchange inside the engine -------------------------------------------------------------------
+// One process per GPU.  librccl is dlopen'ed here (the copy already mapped into the process -- PyTorch-ROCm's -- if there is one,
+// else ROCm's), so libgpe_hip.so has no link-time dependency on it and single-GPU users never load it.
+static int rccl_load(gpe_engine* e) {
+    if (e->rccl.dl) return GPE_OK;
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;      // reuse a mapped copy
+    if (!h) for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!h) FAIL(e, GPE_ERR_STATE, "librccl.so not found: %s", dlerror());
+    e->rccl.dl = h;
+    *(void**)&e->rccl.GetUniqueId = dlsym(h, "ncclGetUniqueId");
+    *(void**)&e->rccl.CommInitRank = dlsym(h, "ncclCommInitRank");
+    *(void**)&e->rccl.CommDestroy = dlsym(h, "ncclCommDestroy");
+    *(void**)&e->rccl.AllReduce = dlsym(h, "ncclAllReduce");
+    *(void**)&e->rccl.GetErrorString = dlsym(h, "ncclGetErrorString");
+    if (!e->rccl.GetUniqueId || !e->rccl.CommInitRank || !e->rccl.CommDestroy || !e->rccl.AllReduce || !e->rccl.GetErrorString) {
+        e->rccl.dl = nullptr;
+        FAIL(e, GPE_ERR_STATE, "librccl.so lacks a required symbol");
+    }
+    return GPE_OK;
+}
+#define RCCLCHK(e, call)                                                                                             \
+    do {                                                                                                             \
+        ncclResult_t _r = (call);                                                                                    \
+        if (_r != ncclSuccess) FAIL(e, GPE_ERR_HIP, "%s:%d: %s -> %s", __FILE__, __LINE__, #call, (e)->rccl.GetErrorString(_r)); \
+    } while (0)
+
+int gpe_comm_unique_id(gpe_engine* e, void* out128) {
+    if (!e || !out128) return GPE_ERR_INVALID;
+    int rc = rccl_load(e);
+    if (rc) return rc;
+    static_assert(sizeof(ncclUniqueId) == GPE_COMM_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId id;
+    RCCLCHK(e, e->rccl.GetUniqueId(&id));
+    memcpy(out128, &id, sizeof id);
+    return GPE_OK;
+}
+
+int gpe_comm_init(gpe_engine* e, const void* id128, int rank, int world) {
+    if (!e || !id128 || world < 1 || rank < 0 || rank >= world) return GPE_ERR_INVALID;
+    if (e->comm) FAIL(e, GPE_ERR_STATE, "communicator already initialised");
+    if (world != (e->cfg.world_size > 0 ? e->cfg.world_size : 1))
+        FAIL(e, GPE_ERR_INVALID, "comm world %d != gpe_config.world_size %d", world, e->cfg.world_size);
+    int rc = rccl_load(e);
+    if (rc) return rc;
+    HIPCHK(e, hipSetDevice(e->device));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    RCCLCHK(e, e->rccl.CommInitRank(&e->comm, world, id, rank));
+    e->comm_rank = rank; e->comm_world = world;
+    HIPCHK(e, hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
+    HIPCHK(e, hipEventCreateWithFlags(&e->ev_x0, hipEventDisableTiming));
+    HIPCHK(e, hipEventCreateWithFlags(&e->ev_x1, hipEventDisableTiming));
+    e->ev_bucket.resize(e->nd.n_lin);
+    for (auto& ev : e->ev_bucket) HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    e->dp_collectives = 0;
+    return GPE_OK;
+}
+
+int gpe_comm_destroy(gpe_engine* e) {
+    if (!e) return GPE_ERR_INVALID;
+    if (!e->comm) return GPE_OK;
+    (void)hipStreamSynchronize(e->stream);
+    (void)hipStreamSynchronize(e->comm_stream);
+    (void)e->rccl.CommDestroy(e->comm);
+    e->comm = nullptr;
+    (void)hipStreamDestroy(e->comm_stream); e->comm_stream = nullptr;
+    (void)hipEventDestroy(e->ev_x0); (void)hipEventDestroy(e->ev_x1); e->ev_x0 = e->ev_x1 = nullptr;
+    for (hipEvent_t ev : e->ev_bucket) (void)hipEventDestroy(ev);
+    e->ev_bucket.clear();
+    return GPE_OK;
+}
+
+int gpe_comm_info(const gpe_engine* e, int* rank, int* world, int64_t* collectives) {
+    if (!e) return GPE_ERR_INVALID;
+    if (rank) *rank = e->comm ? e->comm_rank : -1;
+    if (world) *world = e->comm ? e->comm_world : 0;
+    if (collectives) *collectives = e->dp_collectives;
+    return GPE_OK;
+}
+
+// all-reduce(sum) buf in place on the exchange stream once everything enqueued on the compute stream so far has finished
+static int dp_allreduce_after(gpe_engine* e, void* buf, size_t count, ncclDataType_t dt, hipEvent_t ev) {
+    HIPCHK(e, hipEventRecord(ev, e->stream));
+    HIPCHK(e, hipStreamWaitEvent(e->comm_stream, ev, 0));
+    RCCLCHK(e, e->rccl.AllReduce(buf, buf, count, dt, ncclSum, e->comm, e->comm_stream));
+    e->dp_collectives++;
+    return GPE_OK;
+}
+static int dp_join(gpe_engine* e) {       // the compute stream continues after everything on the exchange stream
+    HIPCHK(e, hipEventRecord(e->ev_x1, e->comm_stream));
+    HIPCHK(e, hipStreamWaitEvent(e->stream, e->ev_x1, 0));
+    return GPE_OK;
+}
+
+// One synchronous data-parallel step, no host synchronisation: begin -> all-reduce of the 12 double sums -> backward with the
+// gradient all-reduced on the exchange stream (generic set: one bucket per linear map, output map first, behind the remaining
+// reverse pass; fused set: the reverse pass is a single kernel, so one P+4 message) -> clip/Adam (replicated, bit-identical).
+int gpe_step_dp(gpe_engine* e) {
+    if (!e) return GPE_ERR_INVALID;
+    if (!e->comm) FAIL(e, GPE_ERR_STATE, "gpe_step_dp before gpe_comm_init");
+    int rc;
+    if ((rc = gpe_step_begin(e))) return rc;
+    if ((rc = dp_allreduce_after(e, e->sums(), S_COUNT, ncclDouble, e->ev_x0))) return rc;
+    if ((rc = dp_join(e))) return rc;
+    // layer buckets need every map's gradient to be final when its weight kernel ends: no second batch adding to it later
+    e->dp_bucket = e->path == GPE_PATH_GENERIC && e->cfg.w_sym == 0.f && !e->bc_inflight;
+    rc = gpe_step_backward(e);
+    const bool bucketed = e->dp_bucket;
+    e->dp_bucket = false;
+    if (rc) return rc;
+    if (bucketed) rc = dp_allreduce_after(e, e->grad + e->P, GT_COUNT, ncclFloat, e->ev_x0);      // exchange tail (sum r^2)
+    else rc = dp_allreduce_after(e, e->grad, (size_t)e->P + GT_COUNT, ncclFloat, e->ev_x0);
+    if (rc) return rc;
+    if ((rc = dp_join(e))) return rc;
+    return gpe_step_update(e);
+}
+
+int gpe_run_dp(gpe_engine* e, int64_t n_steps) {
+    for (int64_t i = 0; i < n_steps; ++i) {
+        int rc = gpe_step_dp(e);
+        if (rc) return rc;
+    }
     return GPE_OK;
 }
 

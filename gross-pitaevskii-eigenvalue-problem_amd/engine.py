@@ -173,6 +173,45 @@ class Engine:
     def active_path(self) -> int:
         return int(self.lib.gpe_active_path(self._h))
 
+    @property
+    def active_kernels(self) -> dict:
+        """{'fwd': name, 'bwd': name} of the jet forward / reverse kernels the bound collocation batch is dispatched to."""
+        buf = C.create_string_buffer(512)
+        self._chk(self.lib.gpe_active_kernels(self._h, buf, 512))
+        return dict(kv.split("=", 1) for kv in buf.value.decode().split(";"))
+
+    # ---- data-parallel exchange inside the engine (RCCL on the engine's exchange stream) ---------------------------------
+    def comm_init(self, rank: int, world: int, store=None, key: str = "gpe_comm_id"):
+        """Create the engine's own RCCL communicator.  The 128-byte ncclUniqueId travels through `store` (anything with
+        set/get, e.g. the TCPStore of an initialised torch.distributed group, the default when none is given)."""
+        if store is None and world > 1:
+            import torch.distributed as dist
+            store = dist.distributed_c10d._get_default_store()
+        ident = (C.c_ubyte * capi.GPE_COMM_ID_BYTES)()
+        if rank == 0:
+            self._chk(self.lib.gpe_comm_unique_id(self._h, ident))
+            if store is not None:
+                store.set(key, bytes(ident))
+        else:
+            raw = store.get(key)
+            C.memmove(ident, bytes(raw), capi.GPE_COMM_ID_BYTES)
+        self._chk(self.lib.gpe_comm_init(self._h, ident, int(rank), int(world)))
+
+    def comm_info(self) -> dict:
+        r, w, n = C.c_int(), C.c_int(), C.c_int64()
+        self._chk(self.lib.gpe_comm_info(self._h, C.byref(r), C.byref(w), C.byref(n)))
+        return dict(rank=r.value, world=w.value, collectives=n.value)
+
+    def comm_destroy(self):
+        self._chk(self.lib.gpe_comm_destroy(self._h))
+
+    def step_dp(self):
+        """One data-parallel step with both exchanges issued by the engine (no Python between the phases, no host sync)."""
+        self._chk(self.lib.gpe_step_dp(self._h))
+
+    def run_dp(self, n_steps: int):
+        self._chk(self.lib.gpe_run_dp(self._h, int(n_steps)))
+
     # ---- parameters ---------------------------------------------------------------------------------
     def set_params(self, flat):
         a = np.ascontiguousarray(np.asarray(flat, dtype=np.float32).ravel())

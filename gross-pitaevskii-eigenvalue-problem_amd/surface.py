@@ -97,6 +97,13 @@ def _advanced_init(layers, mode, kind) -> np.ndarray:
     return np.concatenate(parts).astype(np.float32)
 
 
+def seeded_reference_init(layers, mode, kind) -> np.ndarray:
+    """The weights a seeded reference run starts from: GrossPitaevskiiPINN(layers) draws nn.Linear's default init from the
+    global RNG, then model.apply(advanced_initialization) overwrites it (refine/...:295-304 ; nb c10:L63-70)."""
+    _default_init(layers)
+    return _advanced_init(layers, mode, kind)
+
+
 class _PINNBase:
     """Parameter container + per-call loss surface.  The training loop does not go through these methods (it drives
     Engine.step / Engine.run); they exist so that code written against the reference class keeps working."""
@@ -656,6 +663,7 @@ box = types.SimpleNamespace(GrossPitaevskiiPINN=_BoxPINN, train_gpe_model=_box_t
 refine = types.SimpleNamespace(GrossPitaevskiiPINN=_RefinePINN, train_gpe_model=_refine_train,
                                advanced_initialization=_refine_advanced_initialization,
                                pretrain_on_analytical_solution=_refine_pretrain,
-                               normalized_wavefunction=_refine_wavefunction)
+                               normalized_wavefunction=_refine_wavefunction, KIND="xavier_normal")
 notebook = types.SimpleNamespace(GrossPitaevskiiPINN=_NotebookPINN, train_gpe_model=_nb_train,
-                                 advanced_initialization=_nb_advanced_initialization, density=_nb_density)
+                                 advanced_initialization=_nb_advanced_initialization, density=_nb_density,
+                                 KIND="xavier_uniform")

@@ -132,6 +132,9 @@ void gpe_destroy(gpe_engine* e);
 const char* gpe_last_error(const gpe_engine* e); /* e may be NULL: last create() error */
 /* 1 = generic kernels, 2 = fused MFMA kernels (what gpe_create selected) */
 int gpe_active_path(const gpe_engine* e);
+/* "fwd=<kernel>;bwd=<kernel>": the jet forward / reverse kernels the bound collocation batch is dispatched to (the engine
+ * picks among several by shape, batch size and the GPE_* tuning switches).  Needs gpe_bind_points first. */
+int gpe_active_kernels(gpe_engine* e, char* buf, size_t n);
 
 /* ---- parameters: model.state_dict() / load_state_dict() (refine/...:299,909,953) --------------- */
 int64_t gpe_param_count(const gpe_engine* e);
@@ -179,6 +182,20 @@ int gpe_exchange_grad(gpe_engine* e, void** d_ptr /* float*  */, int64_t* count)
  * (the first `count` of gpe_exchange_sums() are the all-reduced part), d_grad: >= P + 4 floats. */
 int64_t gpe_exchange_dbl_count(void);
 int gpe_use_external_exchange(gpe_engine* e, void* d_dbl, int64_t n_dbl, void* d_grad, int64_t n_grad);
+/* ---- data-parallel exchange INSIDE the engine: RCCL over xGMI on a dedicated HIP stream ------------------------------------
+ * The reference is single-device (refine/...:12); this is the build's row (e) of SURVEY 8.  One process per GPU:
+ *   rank 0: gpe_comm_unique_id() -> 128 bytes, handed to the other ranks by any out-of-band channel (a torch.distributed
+ *   store, MPI, a file); every rank: gpe_comm_init(id, rank, world) with gpe_config.world_size == world.
+ * gpe_step_dp = gpe_step_begin, ncclAllReduce of the 12 double sums, gpe_step_backward with the gradient all-reduced on the
+ * exchange stream (generic kernel set: one bucket per linear map, output map first, overlapped with the rest of the reverse
+ * pass; fused set: one P+4 message), gpe_step_update.  Nothing synchronises with the host. */
+#define GPE_COMM_ID_BYTES 128
+int gpe_comm_unique_id(gpe_engine* e, void* out128);
+int gpe_comm_init(gpe_engine* e, const void* id128, int rank, int world);
+int gpe_comm_destroy(gpe_engine* e);
+int gpe_comm_info(const gpe_engine* e, int* rank, int* world, int64_t* collectives);   /* rank -1 / world 0: no communicator */
+int gpe_step_dp(gpe_engine* e);
+int gpe_run_dp(gpe_engine* e, int64_t n_steps);
 /* all three phases + synchronise + scalars (single rank) */
 int gpe_step(gpe_engine* e, gpe_scalars* out);
 /* n steps enqueued back to back, no host synchronisation (single rank) */

@@ -23,8 +23,10 @@ Reference anchors (under /root/reference/Gross-Pitaevskii/src/final/refine/ unle
   clip / Adam / schedulers   harmonic_pinn_simulation.py:309-314, 359-361 ; notebook c10:L73-78,L101-103
 Configs 3-5 of BASELINE.json (2D/3D harmonic, complex rotating psi, orthogonality) have no
 reference counterpart: for those this file is the definition ("parity unpinned" by the
-reference; pinned by analytic limits in tests/test_oracle_analytic.py and by the
-torch-autograd restatement oracle/torch_ref.py).
+reference; pinned by the torch-autograd restatement oracle/torch_ref.py in fp64 --
+tests/test_oracle_autograd.py -- and, for the 2D Laplacian / residual of one point, by the
+reference's own 2D class called one point at a time, where its broadcast quirk Q1 is inert:
+tests/golden/fx_2d_ref_points.npz, tests/test_oracle_golden.py).
 """
 from __future__ import annotations
 

@@ -92,7 +92,7 @@ def _potential(pb: go.Problem, x: torch.Tensor, V_pre):
 
 
 def epoch_losses(pb: go.Problem, net: nn.Sequential, X: torch.Tensor, x_bc=None, bc_target=None,
-                 V_pre=None, detach_lambda: bool = False):
+                 V_pre=None, detach_lambda: bool = False, orth=None):
     """X requires grad.  Returns (total, dict of pieces).  Mirrors :332-355 / nb c10:L88-97."""
     N, d = X.shape
     u_pred = net(X)                                          # :332
@@ -154,6 +154,12 @@ def epoch_losses(pb: go.Problem, net: nn.Sequential, X: torch.Tensor, x_bc=None,
         riesz = kinetic_term + potential_term + interaction_term
         total = total + pb.w_riesz * riesz
         pieces['riesz'] = riesz
+    if orth is not None and pb.w_orth != 0.0:                # orthogonality penalty (north star; no reference code):
+        orth_l = 0                                           #   L_orth = sum_j (dx * sum_m psi_j(x_m) u(x_m))^2
+        for j in range(orth.shape[0]):
+            orth_l = orth_l + (pb.dx * torch.sum(orth[j].reshape(-1, 1) * u[:, 0:1])) ** 2
+        total = total + pb.w_orth * orth_l
+        pieces['orth'] = orth_l
     if x_bc is not None and pb.w_bc != 0.0:
         ub = pb.bc_nn_scale * net(x_bc)                      # :202 (quirk Q7: unscaled)
         if pb.base_mode >= 0:

@@ -69,6 +69,16 @@ CASES = {
                                    dx=0.01), 150, True),
     "1d_128x2": (dict(layers=[1, 128, 128, 1], gamma=5.0, base_mode=0, dx=0.02), 130, True),
     "3d_256x2_cfg5like": (dict(layers=[3, 256, 256, 1], gamma=100.0, dx=0.01, omega=(1.0, 1.4, 2.0)), 64, False),
+    # BASELINE configs[4] at its true shape: 6 hidden layers of 256, 3D anisotropic trap, g = 1000.  N = 300 / 4099 make the
+    # split-K weight-gradient kernel of the generic set run 2 / 17 chunks of 256 points with a ragged last chunk and tile.
+    "3d_256x6_cfg5_N300": (dict(layers=[3, 256, 256, 256, 256, 256, 256, 1], gamma=1000.0, dx=0.004, omega=(1.0, 1.4, 2.0)), 300, True),
+    "3d_256x6_cfg5_N4099": (dict(layers=[3, 256, 256, 256, 256, 256, 256, 1], gamma=1000.0, dx=0.0003, omega=(1.0, 1.4, 2.0)), 4099, True),
+    "3d_128x6_N300": (dict(layers=[3, 128, 128, 128, 128, 128, 128, 1], gamma=1000.0, dx=0.004, omega=(1.0, 1.4, 2.0)), 300, True),
+    "3d_128x3_N1000": (dict(layers=[3, 128, 128, 128, 1], gamma=100.0, dx=0.001, omega=(1.0, 1.4, 2.0)), 1000, True),
+    "2d_256x3": (dict(layers=[2, 256, 256, 256, 1], gamma=100.0, dx=0.01), 333, True),
+    "1d_256x2": (dict(layers=[1, 256, 256, 1], gamma=5.0, base_mode=0, dx=0.02), 130, True),
+    # BASELINE configs[0], literally: 1D harmonic trap, g = 0 (linear Schroedinger), 4 x 32 tanh MLP, 2048 points on [-10, 10]
+    "1d_32x4_cfg1_g0_N2048": (dict(layers=[1, 32, 32, 32, 32, 1], gamma=0.0, dx=20.0 / 2047), 2048, True),
     "2d_100x2_odd_width": (dict(layers=[2, 100, 100, 1], gamma=1.0, dx=0.01), 77, False),
     "1d_single_hidden": (dict(layers=[1, 64, 1], gamma=1.0, dx=0.01, base_mode=1), 50, False),
 }
@@ -91,6 +101,16 @@ def _inputs(kw, N, seed=0, scale=0.3):
     return x, flat, x_bc
 
 
+def _scale(kw):
+    """weight scale ~ 2.4 / sqrt(H): keeps tanh out of saturation through deep wide nets, so every jet channel stays O(1)"""
+    w = max(kw["layers"][1:-1])
+    return 0.3 if w <= 64 else (0.15 if w <= 128 else 0.1)
+
+
+# shapes whose whole-network (fused) kernel is not built yet: they run on the generic layer-wise set only
+PENDING_FUSED = {"3d_256x6_cfg5_N300", "3d_256x6_cfg5_N4099", "3d_128x6_N300", "3d_128x3_N1000", "2d_256x3", "1d_256x2"}
+
+
 def _case_params():
     out = []
     for name, (kw, N, fused_ok) in CASES.items():
@@ -103,9 +123,10 @@ def _case_params():
 @pytest.mark.parametrize("name,path", _case_params())
 def test_step_matches_oracle(name, path):
     kw, N, _ = CASES[name]
-    scale = 0.15 if max(kw["layers"][1:-1]) > 64 else 0.3
-    x, flat, x_bc = _inputs(kw, N, scale=scale)
+    x, flat, x_bc = _inputs(kw, N, scale=_scale(kw))
     pb = go.Problem(**kw)
+    if path == "fused" and name in PENDING_FUSED:
+        pytest.skip("no fused kernel for this shape yet (generic set covers it)")
     osc, ograd, ores = go.full_loss_and_grad(pb, flat.astype(np.float64), x.astype(np.float64), x_bc.astype(np.float64))
     ojets, _ = go.mlp_forward(go.unflatten(flat.astype(np.float64), pb.layers), x.astype(np.float64), pb.activation)
     eng = make_engine(pb, flat, x, x_bc, path=PATHS[path])
@@ -520,7 +541,7 @@ def test_side_stream_and_graph_replay_change_nothing(kw, N):
     (dict(layers=[2, 64, 64, 64, 64, 1], gamma=50.0, dx=0.01), 4096,
      [{"GPE_COOP": "1", "GPE_COOP_FWD_MAX_TILES": "0"}, {"GPE_COOP": "1", "GPE_COOP_FWD_MAX_TILES": "1000000000"},
       {"GPE_COOP": "0", "GPE_STAGE_MIN_TILES": "0"}, {"GPE_COOP": "0", "GPE_STAGE_MIN_TILES": "1000000000"},
-      {"GPE_COOP": "0", "GPE_STAGE_MIN_TILES": "0", "GPE_RACC": "0"}]),
+      {"GPE_COOP": "0", "GPE_STAGE_MIN_TILES": "0", "GPE_RACC": "0"}, {"GPE_COOP": "0", "GPE_WLDS": "0"}]),
     (dict(layers=[1, 32, 32, 32, 1], gamma=5.0, base_mode=0, dx=0.01), 1000,
      [{"GPE_COOP": "1"}, {"GPE_COOP": "0", "GPE_STAGE_MIN_TILES": "0"}, {"GPE_COOP": "0", "GPE_STAGE_MIN_TILES": "1000000000"}]),
     (dict(layers=[2, 128, 128, 128, 1], gamma=50.0, dx=0.01), 777,
@@ -531,8 +552,9 @@ def test_kernel_variants_agree(kw, N, envs):
     """The fused path has several kernels for the same two primitives -- cooperative (a workgroup per tile), per-wave-tile with
     LDS-staged weights + register-resident gradients, per-wave-tile unstaged with LDS-atomic gradients, global-atomic slabs for
     H = 128 -- selected by shape and batch size.  One step from the same state must agree to fp32 round-off whichever runs."""
-    scale = 0.15 if max(kw["layers"][1:-1]) > 64 else 0.3
+    scale = _scale(kw)
     ref = None
+    seen = set()
     for env in envs:
         import os
         old = {k: os.environ.get(k) for k in env}
@@ -546,6 +568,8 @@ def test_kernel_variants_agree(kw, N, envs):
                     os.environ.pop(k, None)
                 else:
                     os.environ[k] = v
+        kern = eng.active_kernels
+        seen.add((kern["fwd"], kern["bwd"]))
         sc = eng.step()
         g = eng.get_grad()
         eng.close()
@@ -554,3 +578,162 @@ def test_kernel_variants_agree(kw, N, envs):
         else:
             assert abs(sc["loss"] - ref[0]) <= 2e-6 * abs(ref[0]), env
             assert H.rel_err(g, ref[1]) < 3e-6, env
+    assert len(seen) == len(envs), f"switches selected only {sorted(seen)}"     # every row ran a different kernel pair
+
+
+# ---- orthogonality penalty (north star; no reference code: the oracle is the definition, tests/test_oracle_autograd.py) --------
+ORTH_CASES = {
+    "1d_two_modes": (dict(layers=[1, 64, 64, 64, 1], gamma=3.0, base_mode=2, w_orth=7.0, dx=12 / 799), 800, 2),
+    "2d_one_mode": (dict(layers=[2, 64, 64, 64, 64, 1], gamma=50.0, w_orth=3.0, dx=36 / 2000), 2000, 1),
+    "2d_128_two_modes": (dict(layers=[2, 128, 128, 128, 1], gamma=50.0, w_orth=3.0, dx=36 / 500), 500, 2),
+}
+
+
+def _orth_modes(x, n_o, seed=9):
+    """smooth stand-ins for lower eigenmodes on the points: Gaussians times low polynomials, O(1) amplitudes"""
+    rng = np.random.default_rng(seed)
+    r2 = (x.astype(np.float64) ** 2).sum(axis=1)
+    out = []
+    for j in range(n_o):
+        c = rng.normal(0, 1, x.shape[1] + 1)
+        out.append((c[0] + x.astype(np.float64) @ c[1:]) * np.exp(-0.5 * r2 / (1.0 + j)))
+    return np.stack(out)
+
+
+@pytest.mark.parametrize("name", sorted(ORTH_CASES))
+@pytest.mark.parametrize("path", ["generic", "fused"])
+def test_orthogonality_step_matches_oracle(name, path):
+    kw, N, n_o = ORTH_CASES[name]
+    x, flat, x_bc = _inputs(kw, N, scale=_scale(kw))
+    orth = _orth_modes(x, n_o)
+    pb = go.Problem(**kw)
+    osc, ograd, _ = go.full_loss_and_grad(pb, flat.astype(np.float64), x.astype(np.float64), x_bc.astype(np.float64), orth=orth)
+    assert osc["orth"] > 1e-4 * osc["loss"]            # the term matters in this case
+    eng = make_engine(pb, flat, x, x_bc, path=PATHS[path])
+    for j in range(n_o):
+        eng.bind_orth(j, orth[j].astype(np.float32))
+    rs, _, _ = eng.residual()
+    assert abs(rs["orth"] - osc["orth"]) <= 1e-4 * osc["orth"]
+    sc = eng.step()
+    for k, tol in (("mu", 2e-5), ("loss", 1e-4), ("orth", 1e-4), ("pde", 1e-4)):
+        assert abs(sc[k] - osc[k]) <= tol * max(abs(osc[k]), 1e-6), (k, sc[k], osc[k])
+    assert H.rel_err(eng.get_grad(), ograd) < 5e-5
+    # unbinding restores the plain step
+    for j in range(n_o):
+        eng.bind_orth(j, None)
+    eng.set_params(flat)
+    o0, g0, _ = go.full_loss_and_grad(pb, flat.astype(np.float64), x.astype(np.float64), x_bc.astype(np.float64))
+    sc0 = eng.step()
+    assert sc0["orth"] == 0.0 and abs(sc0["loss"] - o0["loss"]) <= 1e-4 * abs(o0["loss"])
+    assert H.rel_err(eng.get_grad(), g0) < 5e-5
+    eng.close()
+
+
+def test_orthogonality_shard_additivity_two_engines():
+    """The S_ORTH sums ride in the first exchange: two engines on the two halves, buffers summed by hand, equal the full batch."""
+    kw, N, n_o = ORTH_CASES["2d_one_mode"][0], 3001, 2
+    x, flat, x_bc = _inputs(kw, N)
+    orth = _orth_modes(x, n_o).astype(np.float32)
+    pb = go.Problem(**kw, n_global=N)
+    full = make_engine(pb, flat, x, x_bc)
+    for j in range(n_o):
+        full.bind_orth(j, orth[j])
+    ref = full.step()
+    gref = full.get_grad()
+    lo = 1300
+    engs = [make_engine(pb, flat, x[:lo], x_bc, world_size=2), make_engine(pb, flat, x[lo:], x_bc, world_size=2)]
+    for e, sl in zip(engs, (slice(0, lo), slice(lo, N))):
+        for j in range(n_o):
+            e.bind_orth(j, orth[j][sl])
+        e.step_begin()
+    tot = engs[0].exchange_sums + engs[1].exchange_sums
+    for e in engs:
+        e.exchange_sums.copy_(tot)
+        e.step_backward()
+    gt = engs[0].exchange_grad + engs[1].exchange_grad
+    for e in engs:
+        e.exchange_grad.copy_(gt)
+        e.step_update()
+    for e in engs:
+        sc = e.read_scalars()
+        assert abs(sc["orth"] - ref["orth"]) <= 1e-5 * ref["orth"] and ref["orth"] > 0
+        assert abs(sc["loss"] - ref["loss"]) <= 1e-5 * abs(ref["loss"])
+    assert H.rel_err(engs[0].get_grad(), gref) < 1e-5
+    np.testing.assert_array_equal(engs[0].get_params(), engs[1].get_params())
+
+
+# ---- d > 1 pinned by the reference's own 2D class, one point per call (tests/golden/make_golden_2d.py) -------------------------
+@pytest.mark.parametrize("name", ["fx_2d_ref_points_64x4_g500.npz", "fx_2d_ref_points_100x3_g100.npz", "fx_2d_ref_points_128x5_g500.npz"])
+def test_golden_2d_reference_points(name):
+    """HIP jets (u, u_x, u_y, u_xx, u_yy) and H u = -lap u + V u + g u^3 against src/gross_pitaevskii_2D_minimal.py:170-182
+    evaluated one point at a time (quirk Q1 inert).  The reference's Gaussian potential is handed over as a precomputed V."""
+    fx = H.load_fx(name)
+    layers = [int(v) for v in fx["layers"]]
+    pb = go.Problem(layers=layers, kinetic_coeff=1.0, potential=go.POT_PRECOMPUTED, gamma=float(fx["g"]), p=3, dx=0.01)
+    for path in ("generic", "fused"):
+        if path == "fused" and layers[1] == 100:
+            continue
+        eng = Engine(cfg_from_problem(pb, w_bc=0.0, path=PATHS[path]))
+        eng.set_params(fx["flat0"])
+        xt = torch.as_tensor(fx["x"], device="cuda")
+        eng.bind_points(xt, V=torch.as_tensor(fx["V"].astype(np.float32), device="cuda"))
+        jets = eng.forward_jets(xt).cpu().numpy()[:, :, 0]
+        for c, key, tol in ((0, "u", 2e-6), (1, "u_x", 5e-6), (2, "u_y", 5e-6), (3, "u_xx", 2e-5), (4, "u_yy", 2e-5)):
+            assert H.rel_err(jets[c], fx[key]) < tol, (path, key)
+        sc, psi, res = eng.residual()
+        Hu = res.cpu().numpy()[:, 0] + sc["mu"] * psi.cpu().numpy()[:, 0]          # r = H u - mu u
+        assert H.rel_err(Hu, fx["residual"] + fx["lam"] * fx["u"]) < 3e-5, path
+        eng.close()
+
+
+# ---- generic set: VALU, 64x64-tile MFMA and 128x128-tile MFMA kernels are three implementations of the same maps ----------------
+@pytest.mark.parametrize("kw,N", [(CASES["3d_256x6_cfg5_N4099"][0], 4099), (CASES["3d_128x6_N300"][0], 1500)])
+def test_generic_kernel_variants_agree(kw, N):
+    import os
+    ref = None
+    seen = set()
+    for env in ({}, {"GPE_GEN_MFMA2": "0"}, {"GPE_GEN_MFMA": "0"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            x, flat, x_bc = _inputs(kw, N, scale=_scale(kw))
+            eng = make_engine(go.Problem(**kw), flat, x, x_bc, path=gpe_pinn.PATH_GENERIC)
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        kern = eng.active_kernels
+        seen.add((kern["fwd"], kern["bwd"]))
+        sc = eng.step()
+        g = eng.get_grad()
+        eng.close()
+        if ref is None:
+            ref = (sc, g)
+        else:
+            assert abs(sc["loss"] - ref[0]["loss"]) <= 1e-5 * abs(ref[0]["loss"]), env
+            assert abs(sc["mu"] - ref[0]["mu"]) <= 1e-5 * abs(ref[0]["mu"]), env
+            assert H.rel_err(g, ref[1]) < 2e-5, env
+    assert len(seen) == 3, sorted(seen)
+
+
+# ---- native exchange: the engine's own RCCL communicator (world 1 on the one-GPU box: the same code path as N ranks) -----------
+@pytest.mark.parametrize("path", ["generic", "fused"])
+def test_native_rccl_step_equals_plain_step(path):
+    kw = dict(layers=[2, 64, 64, 64, 1], gamma=50.0, dx=0.01)
+    x, flat, x_bc = _inputs(kw, 3000)
+    pb = go.Problem(**kw)
+    a = make_engine(pb, flat, x, x_bc, path=PATHS[path])
+    b = make_engine(pb, flat, x, x_bc, path=PATHS[path])
+    b.comm_init(0, 1)
+    assert b.comm_info()["world"] == 1 and a.comm_info()["world"] == 0
+    for _ in range(3):
+        a.step()
+        b.step_dp()
+    sa, sb = a.read_scalars(), b.read_scalars()
+    assert abs(sa["loss"] - sb["loss"]) <= 1e-6 * abs(sa["loss"]) and abs(sa["mu"] - sb["mu"]) <= 1e-6 * abs(sa["mu"])
+    assert np.abs(a.get_params() - b.get_params()).max() < 1e-6
+    n = b.comm_info()["collectives"]
+    # fused: sums + one gradient message per step; generic: sums + one bucket per linear map + the tail
+    assert n == (3 * 2 if path == "fused" else 3 * (1 + (len(kw["layers"]) - 1) + 1)), n
+    with pytest.raises(gpe_pinn.GPEError):
+        a.step_dp()                                   # no communicator: loud
+    a.close(); b.close()

@@ -189,3 +189,51 @@ def test_paper_notebook_riesz_oplevel(name):
     assert abs(sc["pde"] - float(fx["pde_loss"])) < 5e-4 * float(fx["pde_loss"])
     assert abs(sc["loss"] - float(fx["total"])) < 2e-4 * float(fx["total"])
     assert H.rel_err(grad, fx["grad0"]) < 5e-4
+
+
+# ---- d > 1 pinned by the reference's own 2D class, one point per call (quirk Q1 inert at N = 1) -----------------------------
+FX_2D = ["fx_2d_ref_points_64x4_g500.npz", "fx_2d_ref_points_100x3_g100.npz", "fx_2d_ref_points_128x5_g500.npz"]
+
+
+@pytest.mark.parametrize("name", FX_2D)
+def test_2d_jets_and_Hu_against_reference_points(name):
+    """tests/golden/make_golden_2d.py: src/gross_pitaevskii_2D_minimal.py:170-182 evaluated one point at a time.
+    Oracle (fp64) jets vs the reference's fp32 autograd u_x, u_y, u_xx, u_yy; H u = -lap u + V u + g u^3 vs the reference's
+    residual + lambda_pde u; and the reference's energy-functional lambda_pde = (|grad u|^2 + V u^2 + g u^4)/u^2."""
+    fx = H.load_fx(name)
+    layers = [int(v) for v in fx["layers"]]
+    g = float(fx["g"])
+    x = fx["x"].astype(np.float64)
+    flat = fx["flat0"].astype(np.float64)
+    jets, _ = go.mlp_forward(go.unflatten(flat, layers), x, 0)
+    assert H.rel_err(jets[0][:, 0], fx["u"]) < 2e-6
+    assert H.rel_err(jets[1][:, 0], fx["u_x"]) < 5e-6 and H.rel_err(jets[2][:, 0], fx["u_y"]) < 5e-6
+    assert H.rel_err(jets[3][:, 0], fx["u_xx"]) < 2e-5 and H.rel_err(jets[4][:, 0], fx["u_yy"]) < 2e-5
+    # the oracle's head with the reference's V fed as a precomputed potential, kinetic coefficient 1, gamma u^3
+    pb = go.Problem(layers=layers, kinetic_coeff=1.0, potential=go.POT_PRECOMPUTED, gamma=g, p=3)
+    h = go.head_pde(pb, x, jets, V_pre=fx["V"])
+    Hu_ref = fx["residual"] + fx["lam"] * fx["u"]
+    assert H.rel_err(h["Hu"][:, 0], Hu_ref) < 2e-5
+    u = jets[0][:, 0]
+    lam_o = (jets[1][:, 0] ** 2 + jets[2][:, 0] ** 2 + fx["V"] * u ** 2 + g * u ** 4) / u ** 2
+    big = np.abs(fx["u"]) > 1e-2            # the quotient is ill-conditioned where u ~ 0
+    assert np.abs(lam_o[big] / fx["lam"][big] - 1).max() < 2e-4
+
+
+# ---- a13: seeded initialisation equals the fixtures' flat0 bit for bit -------------------------------------------------------
+def test_advanced_initialization_bit_exact():
+    """surface._advanced_init after torch.manual_seed(seed) + default nn.Linear init == the reference's
+    model.apply(advanced_initialization) (refine/harmonic_pinn_simulation.py:636-647 ; nb c18), both flavours."""
+    import torch
+    from gpe_pinn import surface
+    seeds = {"fx_refine_m0_g0_64x3.npz": 0, "fx_refine_m0_g50_64x3.npz": 1, "fx_refine_m2_g10_32x4.npz": 2,
+             "fx_refine_m5_g4_p4_64x4.npz": 3, "fx_nb_m0_g1_p3_32x4.npz": 0, "fx_nb_m0_g100_p3_64x4.npz": 1,
+             "fx_nb_m0_g1_p2_64x3.npz": 2}
+    for name, seed in seeds.items():
+        fx = H.load_fx(name)
+        layers = [int(v) for v in fx["layers"]]
+        mode = int(fx["mode"])
+        torch.manual_seed(seed)
+        flavour = surface.refine if "refine" in name else surface.notebook
+        flat = surface.seeded_reference_init(layers, mode, flavour.KIND)
+        np.testing.assert_array_equal(flat, fx["flat0"], err_msg=name)
