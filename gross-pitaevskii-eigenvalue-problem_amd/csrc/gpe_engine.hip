@@ -24,6 +24,7 @@
 #include "gpe_head.h"
 #include "gpe_generic.h"
 #include "gpe_fused.h"
+#include "gpe_wide_api.h"
 
 static thread_local std::string g_create_error;
 
@@ -197,6 +198,8 @@ struct Batch {
     float* Hu = nullptr;
     float* ux = nullptr;           // [ld] du/dx (Riesz term, 1D)
     float* stored = nullptr;       // fused: fragment-native stored activations
+    float* Z0 = nullptr;           // wide set: adjoint-jet ping-pong buffers [tile][C][H/16][256]
+    float* Z1 = nullptr;
     std::vector<float*> S;         // generic: per hidden layer [C][H][ld]
     float* A0 = nullptr;           // generic adjoint ping/pong [C][maxW][ld]
     float* A1 = nullptr;
@@ -213,6 +216,7 @@ struct gpe_engine {
     hipStream_t stream = nullptr;
     int path = GPE_PATH_GENERIC;
     int H = 0;                     // uniform hidden width (fused)
+    bool wide = false;             // fused path served by the wide kernel set (gpe_wide.h): H = 256, or H = 128 in 3D
     int P = 0, Ppad = 0;
     float base_norm = 1.f;
     float *theta = nullptr, *am = nullptr, *av = nullptr, *grad = nullptr;   // grad: P + GT_COUNT
@@ -321,6 +325,11 @@ static int setup_batch(gpe_engine* e, Batch& b, const float* x, int64_t n, int C
         int64_t ntiles = (n + 15) / 16;
         size_t cnt = with_store ? (size_t)ntiles * (L - 1) * C * e->H * 16 : 0;     // forward-only batches keep nothing
         if ((rc = dev_alloc(e, &b, &b.stored, cnt ? cnt : 4))) return rc;
+        if (e->wide && with_store) {
+            const size_t zc = (size_t)ntiles * C * e->H * 16;
+            if ((rc = dev_alloc(e, &b, &b.Z0, zc))) return rc;
+            if ((rc = dev_alloc(e, &b, &b.Z1, zc))) return rc;
+        }
     } else {
         int maxW = 1;
         for (int h = 0; h < L; ++h) {
@@ -342,7 +351,7 @@ static int setup_batch(gpe_engine* e, Batch& b, const float* x, int64_t n, int C
 #ifdef GPE_FAST_BUILD    // kernel-tuning builds (tools/build_variant.sh): only what the 2D n_out = 1, H = 64 workloads launch
 #define DISPATCH_TRAIN(bb, ...)                                        \
     switch ((bb).C * 10 + (bb).E) {                                    \
-        CE_CASE(1, 0, __VA_ARGS__) CE_CASE(4, 1, __VA_ARGS__)          \
+        CE_CASE(1, 0, __VA_ARGS__) CE_CASE(4, 1, __VA_ARGS__) CE_CASE(5, 1, __VA_ARGS__)         \
         default: FAIL(e, GPE_ERR_INVALID, "fast build: channels (%d,%d) not compiled", (bb).C, (bb).E); \
     }
 #define DISPATCH_FWD(bb, ...) DISPATCH_TRAIN(bb, __VA_ARGS__)
@@ -567,6 +576,14 @@ static void prof_mark(gpe_engine* e, int kind, bool start) {
     (void)hipEventRecord(e->ev_pool[2 * idx + (start ? 0 : 1)], e->stream);
 }
 
+static WideCall wide_call(gpe_engine* e, Batch& b) {
+    WideCall a;
+    a.nd = e->nd; a.theta = e->theta; a.Wpk = e->Wpk; a.WpkT = e->WpkT; a.pts = b.pts; a.stored = b.stored; a.O = b.O; a.Ob = b.Ob;
+    a.Z0 = b.Z0; a.Z1 = b.Z1; a.gslab = e->gslab; a.N = b.n; a.ld = b.ld; a.Ppad = e->Ppad; a.H = e->H; a.C = b.C; a.E = b.E;
+    a.num_cu = e->num_cu; a.stream = e->stream;
+    return a;
+}
+
 static int mlp_forward(gpe_engine* e, Batch& b, bool store) {
     if (b.n <= 0) return GPE_OK;
     const bool mark = e->prof && (&b == &e->main);
@@ -575,6 +592,13 @@ static int mlp_forward(gpe_engine* e, Batch& b, bool store) {
         if (rc) return rc;
         unsigned grid = fused_grid(e, b.n, 4, 2);
         if (mark) prof_mark(e, 0, true);
+        if (e->wide) {
+            const int wr = wide_forward(wide_call(e, b), store ? 1 : 0);
+            if (wr < 0) FAIL(e, GPE_ERR_INVALID, "wide kernel set: channels (%d,%d) / n_out %d not compiled", b.C, b.E, e->nd.n_out);
+            if (wr) FAIL(e, GPE_ERR_HIP, "w_forward launch: %s", hipGetErrorString((hipError_t)wr));
+            if (mark) prof_mark(e, 0, false);
+            return GPE_OK;
+        }
 #ifdef GPE_FAST_BUILD
         if (e->H != 64 || e->nd.n_out != 1) FAIL(e, GPE_ERR_INVALID, "fast build: only H = 64, n_out = 1 compiled");
         DISPATCH_FWD(b, launch_f_forward<64, CC, EE>(e, b, grid, store ? 1 : 0));
@@ -636,6 +660,13 @@ static int mlp_backward(gpe_engine* e, Batch& b, bool close = false, bool assign
         const bool mark = e->prof && (&b == &e->main);
         if (mark) prof_mark(e, 1, true);
         int nred = (int)grid;
+        if (e->wide) {
+            if (!b.Z0) FAIL(e, GPE_ERR_STATE, "reverse pass on a forward-only batch");
+            const int wr = wide_backward(wide_call(e, b));
+            if (wr < 0) FAIL(e, GPE_ERR_INVALID, "wide kernel set: channels (%d,%d) / n_out %d not compiled", b.C, b.E, e->nd.n_out);
+            if (wr) FAIL(e, GPE_ERR_HIP, "wide reverse launch: %s", hipGetErrorString((hipError_t)wr));
+            nred = wide_groups(e->H, b.n, e->num_cu);
+        } else {
 #ifdef GPE_FAST_BUILD
         if (e->H != 64 || e->nd.n_out != 1) FAIL(e, GPE_ERR_INVALID, "fast build: only H = 64, n_out = 1 compiled");
         DISPATCH_TRAIN(b, launch_f_backward<64, CC, EE>(e, b, grid, lds));
@@ -664,6 +695,7 @@ static int mlp_backward(gpe_engine* e, Batch& b, bool close = false, bool assign
         else if (e->H == 64) { DISPATCH_TRAIN(b, launch_f_backward<64, CC, EE>(e, b, grid, lds)); }
         else            { DISPATCH_TRAIN(b, launch_f_backward<32, CC, EE>(e, b, grid, lds)); }
 #endif
+        }
         if (mark) prof_mark(e, 1, false);
         HIPCHK(e, hipGetLastError());
         const float* add = nullptr;
@@ -830,7 +862,11 @@ int gpe_active_kernels(gpe_engine* e, char* buf, size_t n) {
     const Batch& b = e->main;
     char f[160], r[160];
     const int maps = e->nd.n_lin - 2;
-    if (e->path == GPE_PATH_FUSED) {
+    if (e->path == GPE_PATH_FUSED && e->wide) {
+        snprintf(f, sizeof f, "w_forward<%d,%d,%d,%d>", e->H, b.C, b.E, e->nd.n_out);
+        snprintf(r, sizeof r, "w_bwd_out<%d,%d,%d,%d,%d> + %d x w_bwd_map<%d,%d,%d,%d>", e->H, b.C, b.E, e->nd.n_out, e->H / 128, maps,
+                 e->H, b.C, b.E, e->H / 128);
+    } else if (e->path == GPE_PATH_FUSED) {
         const bool fc = fwd_coop(e, b) && (e->H <= 64 || b.C <= 4);
         if (fc) snprintf(f, sizeof f, "f_forward_coop<%d,%d,%d,%d,%d>", e->H, b.C, b.E, e->nd.n_out, maps > 5 ? 5 : maps);
         else snprintf(f, sizeof f, "f_forward<%d,%d,%d,%d,%s>", e->H, b.C, b.E, e->nd.n_out,
@@ -896,9 +932,11 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
     const int Lh = c.n_layers - 2;
     size_t lds_need = ((size_t)e->Ppad + (size_t)(8 + c.n_layers + 2) * c.layers[1] + 8 + 4 * (dim + 2) * F_TILE) * sizeof(float);
     bool fused_ok = uniform && (H == 32 || H == 64) && Lh >= 2 && lds_need <= 160 * 1024;
-    if (uniform && H == 128 && Lh >= 2 && dim <= 2) fused_ok = true;          // wide variant: global-atomic gradient slabs
+    if (uniform && H == 128 && Lh >= 2 && dim <= 2) fused_ok = true;          // cooperative kernels, weights streamed from L2
+    const char* envw = getenv("GPE_WIDE");                                     // 1: H = 128 takes the wide set in every dimension
+    if (uniform && Lh >= 2 && (H == 256 || (H == 128 && (dim == 3 || (envw && atoi(envw) != 0))))) { fused_ok = true; e->wide = true; }
     if (c.path == GPE_PATH_FUSED && !fused_ok)
-        CFAIL("fused path needs >=2 hidden layers of one width: 32 or 64 (P*4 <= 160KB LDS), or 128 with dim <= 2");
+        CFAIL("fused path needs >=2 hidden layers of one width: 32 or 64 (P*4 <= 160KB LDS), 128 or 256");
     e->path = (c.path == GPE_PATH_GENERIC || !fused_ok) ? GPE_PATH_GENERIC : GPE_PATH_FUSED;
     e->H = H;
 #undef CFAIL
@@ -921,7 +959,8 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
               alloc((void**)&e->hist, (size_t)e->cap * sizeof(gpe_scalars)) && alloc((void**)&e->last, sizeof(gpe_scalars)) &&
               alloc((void**)&e->orth_dev, 8 * sizeof(float*));
     if (ok && e->path == GPE_PATH_FUSED) {
-        e->nslab = (H == 128) ? std::max(e->nslab_g, e->num_cu) : e->num_cu * 2;     // H = 128: 16 atomic slabs, or one per workgroup (cooperative)
+        e->nslab = (H >= 128) ? std::max(e->nslab_g, e->num_cu) : e->num_cu * 2;     // H = 128: 16 atomic slabs, or one per workgroup (cooperative)
+        if (e->wide) wide_init();
         ok = alloc((void**)&e->Wpk, (size_t)(Lh - 1) * H * H * 4) && alloc((void**)&e->WpkT, (size_t)(Lh - 1) * H * H * 4) &&
              alloc((void**)&e->gslab, (size_t)e->nslab * e->Ppad * 4);
         if (ok) {

@@ -26,7 +26,7 @@
 #pragma once
 #include "gpe_common.h"
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+#include "gpe_mfma_util.h"
 
 #ifndef GPE_FWD_WAVES
 #define GPE_FWD_WAVES 2      // waves per SIMD the forward kernel is compiled for (C <= 5)
@@ -34,84 +34,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef GPE_BWD_WAVES
 #define GPE_BWD_WAVES 2
 #endif
-
-#define F_PITCH 20   // floats per row of a transposition tile (16 + 4 pad; rows stay 16-B aligned)
-
-GPE_DEV void wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// sum over the 16 lanes of a DPP row (lanes with equal lane>>4); result valid in every lane of the row.
-// Four v_add_f32 with DPP operands (quad_perm xor1, xor2, row_half_mirror, row_mirror): no LDS, no waitcnt.
-template <int CTRL>
-GPE_DEV float dpp_mov(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-GPE_DEV float row_sum16(float v) {
-    v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
-    v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
-    v += dpp_mov<0x141>(v);   // row_half_mirror
-    v += dpp_mov<0x140>(v);   // row_mirror
-    return v;
-}
-
-// 16 values per lane, 16 lanes per DPP row: lane m of every row returns sum_{lanes of the row} v[m] -- a butterfly that
-// halves the live values each step (row_mirror, row_half_mirror, quad xor 2, quad xor 1): 30 DPP adds + 15 selects for what
-// 16 row_sum16 calls did in 64 DPP adds, and the 16 sums land on 16 different lanes, so ONE LDS atomic instruction (64 distinct
-// addresses) replaces 16 four-lane ones (ds_add_f32 costs ~100 cycles of the wave whatever the lane count).
-GPE_DEV float row_reduce_pick16(const float (&v)[16], int m) {
-    const bool b3 = (m & 8) != 0, b2 = (m & 4) != 0, b1 = (m & 2) != 0, b0 = (m & 1) != 0;
-    float a8[8], a4[4], a2[2];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float lo = v[i] + dpp_mov<0x140>(v[i]), hi = v[i + 8] + dpp_mov<0x140>(v[i + 8]);
-        a8[i] = b3 ? hi : lo;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float lo = a8[i] + dpp_mov<0x141>(a8[i]), hi = a8[i + 4] + dpp_mov<0x141>(a8[i + 4]);
-        a4[i] = b2 ? hi : lo;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const float lo = a4[i] + dpp_mov<0x4E>(a4[i]), hi = a4[i + 2] + dpp_mov<0x4E>(a4[i + 2]);
-        a2[i] = b1 ? hi : lo;
-    }
-    const float lo = a2[0] + dpp_mov<0xB1>(a2[0]), hi = a2[1] + dpp_mov<0xB1>(a2[1]);
-    return b0 ? hi : lo;
-}
-// NF (= H/4) per-lane values, value f belonging to feature 16(f>>2) + 4q + (f&3): add their sums over the tile's 16 points to
-// dst[feature * stride]; chunks of 16 values, one atomic instruction per chunk.
-template <int NF>
-GPE_DEV void row_reduce_add(const float (&v)[NF], float* dst, int stride, int m, int q) {
-#pragma unroll
-    for (int f0 = 0; f0 < NF; f0 += 16) {
-        float c[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) c[i] = (f0 + i < NF) ? v[(f0 + i < NF) ? f0 + i : 0] : 0.f;
-        const float t = row_reduce_pick16(c, m);
-        const int fi = f0 + m;
-        if (fi < NF) atomicAdd(&dst[(16 * (fi >> 2) + 4 * q + (fi & 3)) * stride], t);
-    }
-}
-
-// tile held point-on-lane (lane (m,q) reg r <-> row 4q+r, col m)  ->  feature-on-lane
-// (lane (i,q') element s <-> row i, col 4q'+s)
-// C tiles at once through C wave-private LDS tiles: one fence pair per batch instead of per tile.
-#define F_TILE (16 * F_PITCH)
-template <int C>
-GPE_DEV void tiles_transpose(const f32x4 (&v)[C], f32x4 (&o)[C], float* T, int m, int q) {
-    wave_lds_fence();
-#pragma unroll
-    for (int c = 0; c < C; ++c)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) T[c * F_TILE + (4 * q + r) * F_PITCH + m] = v[c][r];
-    wave_lds_fence();
-#pragma unroll
-    for (int c = 0; c < C; ++c) o[c] = *reinterpret_cast<const f32x4*>(&T[c * F_TILE + m * F_PITCH + 4 * q]);
-}
 
 // pack hidden-hidden weights (linear maps 1..L-1) in MFMA fragment order.
 //   Wpk [j-1][nt][kt][lane][s] = W_j[16nt + (lane&15)][16kt + 4(lane>>4) + s]      (forward A operand)
@@ -143,48 +65,6 @@ __global__ void k_begin(NetDesc nd, int H, const float* __restrict__ theta, floa
     if (idx < n_dbl) dbl[idx] = 0.0;
     if (idx < n_grad) grad[idx] = 0.f;
     if (idx < n_bc) grad_bc[idx] = 0.f;
-}
-
-// ---- layer 0 helpers ---------------------------------------------------------------------------------------------
-// W0 ([H][dim], dim <= 3) and b0 are staged once per workgroup into LDS as w0s[4][H]: rows 0..2 = W0^T zero-padded to
-// three coordinates, row 3 = b0.  With the point coordinates zero-padded too, layer 0 is branch-free for any dim.
-// Behind it, in the same LDS block: the hidden biases b_1..b_{L-1} ([L-1][H]), the output weights ([n_out][H]) and the
-// output bias -- every small operand the per-tile code reads, so that no global (L2-latency) load sits inside a tile.
-GPE_DEV int small_count(const NetDesc& nd, int H) { return (4 + (nd.n_lin - 2) + nd.n_out) * H + 4; }
-template <int H>
-GPE_DEV void stage_layer0(float* w0s, const float* __restrict__ theta, const NetDesc& nd, int nthr) {
-    const int L = nd.n_lin - 1;
-    for (int i = threadIdx.x; i < 4 * H; i += nthr) {
-        const int k = i / H, n = i % H;
-        float v;
-        if (k == 3) v = theta[nd.offB[0] + n];
-        else v = (k < nd.dim) ? theta[nd.offW[0] + n * nd.dim + k] : 0.f;
-        w0s[i] = v;
-    }
-    for (int i = threadIdx.x; i < (L - 1) * H; i += nthr) w0s[4 * H + i] = theta[nd.offB[1 + i / H] + i % H];
-    for (int i = threadIdx.x; i < nd.n_out * H; i += nthr) w0s[(4 + L - 1) * H + i] = theta[nd.offW[L] + i];
-    for (int i = threadIdx.x; i < nd.n_out; i += nthr) w0s[(4 + L - 1 + nd.n_out) * H + i] = theta[nd.offB[L] + i];
-}
-
-// stored-equivalent (t, z_k, z_kk) of hidden layer 0 for features 16nt+4q+r, recomputed from the point coordinates
-template <int H, int C, int E>
-GPE_DEV void layer0_st(const float* w0s, const float (&xv)[3], int nt, int q, f32x4 (&st)[C]) {
-    constexpr int D = C - 1 - E;
-    const int o = 16 * nt + 4 * q;
-    const f32x4 w0 = *reinterpret_cast<const f32x4*>(&w0s[o]);
-    const f32x4 w1 = *reinterpret_cast<const f32x4*>(&w0s[H + o]);
-    const f32x4 w2 = *reinterpret_cast<const f32x4*>(&w0s[2 * H + o]);
-    const f32x4 bb = *reinterpret_cast<const f32x4*>(&w0s[3 * H + o]);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float z = fmaf(w2[r], xv[2], fmaf(w1[r], xv[1], fmaf(w0[r], xv[0], bb[r])));
-        st[0][r] = gpe_tanh(z);
-        if constexpr (D >= 1) st[1][r] = w0[r];
-        if constexpr (D >= 2) st[2][r] = w1[r];
-        if constexpr (D >= 3) st[3][r] = w2[r];
-#pragma unroll
-        for (int e = 0; e < E; ++e) st[1 + D + e][r] = 0.f;      // a linear map has no second derivatives
-    }
 }
 
 // WLDS: the packed hidden-hidden weights ((L-1)*H*H floats) are staged once per workgroup into LDS and the MFMA A
@@ -792,21 +672,6 @@ __global__ __launch_bounds__(H * 4, 2) void f_forward_coop(NetDesc nd, const flo
 // fragments, B operand of W^T z for every wave) and the transposed activation jets X^T (B operand of dW += Z X^T).
 // Elementwise work (recompute, activation adjoint), bias / output / layer-0 gradients are local to a slice.
 // Gradient slabs: H x H rows straight from the accumulators (each wave owns its rows: plain stores); small parameters via LDS.
-GPE_DEV void row_reduce4_add(const float (&v)[4], float* dst16, int m, int q) {
-    // sum over the 16 point lanes of 4 per-lane values (features 4q+r of the slice); total of value r lands on lanes m>>2 == r
-    const bool b3 = (m & 8) != 0, b2 = (m & 4) != 0;
-    float a2[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const float lo = v[i] + dpp_mov<0x140>(v[i]), hi = v[i + 2] + dpp_mov<0x140>(v[i + 2]);
-        a2[i] = b3 ? hi : lo;
-    }
-    const float lo = a2[0] + dpp_mov<0x141>(a2[0]), hi = a2[1] + dpp_mov<0x141>(a2[1]);
-    float t = b2 ? hi : lo;
-    t += dpp_mov<0x4E>(t);
-    t += dpp_mov<0xB1>(t);
-    if ((m & 3) == 0) atomicAdd(&dst16[4 * q + (m >> 2)], t);
-}
 
 template <int H, int C, int E, int NOUT, int NHH>
 __global__ __launch_bounds__(H * 4, 2) void f_backward_coop(NetDesc nd, const float* __restrict__ theta,

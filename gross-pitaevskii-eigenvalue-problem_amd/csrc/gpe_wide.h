@@ -1,0 +1,482 @@
+// gpe_wide.h -- "wide" jet-MLP kernels for gfx950 (CDNA4): hidden width H = 256 (BASELINE configs[4], [3,256x6,1]) and
+// H = 128 with five jet channels (3D), where one H x H weight gradient no longer fits beside the adjoint chain in a
+// workgroup's registers.  Same numerics, same stored-activation format and the same packed weights as gpe_fused.h.
+//
+// Decomposition (every kernel: 512-thread workgroups = 8 waves = 2 per SIMD, one workgroup per CU, persistent over tiles of
+// 16 points; the H x H maps run on v_mfma_f32_16x16x4_f32, exact fp32):
+//   w_forward    whole network.  Wave w owns the output features [16 w RT, 16 (w+1) RT), RT = H/128 row tiles; the activation
+//                jets of a layer are all-gathered through ONE LDS buffer [C][H/16][256] (80 KB at H = 256, C = 5: two
+//                barriers per layer); the W rows of the wave stream from L2 (packed fragments, double-buffered chunks of 4
+//                K tiles); (t, z_k, z_L) are stored fragment-native exactly as f_forward does.
+//   w_bwd_out    output layer: dW_out, db_out, adjoint + activation adjoint of the last hidden layer -> zbar_{L-1} in HBM
+//                ([tile][C][H/16][256], fragment-native).  VALU only.
+//   w_bwd_map    ONE hidden->hidden map j per launch, top down:  zbar_j (HBM) -> abar = W_j^T zbar_j (MFMA), activation
+//                adjoint -> zbar_{j-1} (HBM; for j = 1 the layer-0 gradients instead), dW_j += Zbar_j X_{j-1}^T (MFMA) kept in
+//                accumulator registers across all tiles of the workgroup.  The 256 x 256 gradient does not fit 512 lanes
+//                beside the chain, so the COLUMNS of dW_j are split over NSPLIT = 2 workgroups that share the tiles: each
+//                computes abar / zbar_{j-1} / X for its half of the layer-(j-1) features (no duplicated MFMA work, no
+//                cross-workgroup synchronisation; only zbar_j is read twice -- placed on the same XCD so the second read is
+//                an L2 hit) and owns dW_j[:, its half]: 64 accumulator registers per lane.
+// Per tile and map the adjoint jets cross HBM once in each direction (80 KB at H = 256): 240 KB per 10 240 MFMAs, 1.7 TB/s at
+// the full matrix rate -- a quarter of what HBM sustains, against the generic set's three launches and 61 KB/point per map.
+//
+// Replaces K1-K3, K12 of SURVEY 2.3 (refine/harmonic_pinn_simulation.py:121-125,158-172,358) for BASELINE configs[4];
+// Laplacian template src/gross_pitaevskii_2D.py:183-195 extended to d = 3.
+#pragma once
+#include "gpe_mfma_util.h"
+
+#define W_NW 8            // waves per workgroup
+#define W_KC 4            // K tiles per streamed weight chunk
+
+template <int H, int C>
+__host__ __device__ constexpr int w_fwd_lds_floats(int small, int nout) { return small + C * (H / 16) * 256 + W_NW * nout * C * 16; }
+
+// ---- forward ---------------------------------------------------------------------------------------------------------------
+template <int H, int C, int E, int NOUT>
+__global__ __launch_bounds__(512, 2) void w_forward(NetDesc nd, const float* __restrict__ theta,
+                                                    const float* __restrict__ Wpk, Pts x, float* __restrict__ stored,
+                                                    float* __restrict__ O, int64_t N, int64_t ld, int store_acts) {
+    constexpr int D = C - 1 - E, NT = H / 16, RT = NT / W_NW, NTHR = 64 * W_NW;
+    static_assert(NT % W_NW == 0, "H must be a multiple of 128");
+    extern __shared__ __attribute__((aligned(16))) float lds_w[];
+    float* w0s = lds_w;
+    float* AB = w0s + ((small_count(nd, H) + 3) & ~3);          // [C][NT][256]
+    float* OP = AB + C * NT * 256;                              // [W_NW][NOUT][C][16]
+    const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4, w = threadIdx.x >> 6;
+    const int L = nd.n_lin - 1;
+    const int dim = nd.dim;
+    const float shift = nd.shift;
+    const int64_t ntiles = (N + 15) >> 4;
+    stage_layer0<H>(w0s, theta, nd, NTHR);
+    __syncthreads();
+    const float* Wo = w0s + (4 + L - 1) * H;
+    const float* bo = w0s + (4 + L - 1 + NOUT) * H;
+    const float* wbase = Wpk;
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        asm volatile("" : "+s"(wbase));                        // keep the (tile-invariant) weight loads inside the loop
+        const int64_t pm = tile * 16 + m;
+        const bool valid = pm < N;
+        const int64_t pl = valid ? pm : N - 1;
+        float xv[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) if (k < dim) xv[k] = pts_at(x, pl, dim, k);
+        f32x4 a[RT][C];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {                      // layer 0 (K = dim <= 3): VALU, own slice
+            f32x4 st[C];
+            layer0_st<H, C, E>(w0s, xv, w * RT + rt, q, st);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float zk[D > 0 ? D : 1], zkk[E > 0 ? E : 1], av[C];
+#pragma unroll
+                for (int jd = 0; jd < D; ++jd) zk[jd] = st[1 + jd][r];
+#pragma unroll
+                for (int e = 0; e < E; ++e) zkk[e] = 0.f;
+                act_from_stored<D, E>(st[0][r], zk, zkk, shift, av);
+#pragma unroll
+                for (int c = 0; c < C; ++c) a[rt][c][r] = av[c];
+            }
+        }
+        for (int j = 1; j < L; ++j) {
+            const float* Wp = wbase + (size_t)(j - 1) * H * H;
+            auto load_w = [&](int rt, int kt) {
+                return *reinterpret_cast<const f32x4*>(&Wp[(((w * RT + rt) * NT + kt) * 64 + lane) * 4]);
+            };
+            f32x4 wn[W_KC][RT];
+#pragma unroll
+            for (int i = 0; i < W_KC; ++i)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) wn[i][rt] = load_w(rt, i);      // first chunk: in flight across the barriers
+            __syncthreads();                                    // every wave is done reading AB (previous layer / tile)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int c = 0; c < C; ++c) *reinterpret_cast<f32x4*>(&AB[(c * NT + w * RT + rt) * 256 + lane * 4]) = a[rt][c];
+            __syncthreads();
+            f32x4 acc[RT][C];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                acc[rt][0] = *reinterpret_cast<const f32x4*>(&w0s[(4 + (j - 1)) * H + 16 * (w * RT + rt) + 4 * q]);      // b_j
+#pragma unroll
+                for (int c = 1; c < C; ++c) acc[rt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int k0 = 0; k0 < NT; k0 += W_KC) {
+                f32x4 wv[W_KC][RT];
+#pragma unroll
+                for (int i = 0; i < W_KC; ++i)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) wv[i][rt] = wn[i][rt];
+                if (k0 + W_KC < NT) {
+#pragma unroll
+                    for (int i = 0; i < W_KC; ++i)
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt) wn[i][rt] = load_w(rt, k0 + W_KC + i);
+                }
+#pragma unroll
+                for (int i = 0; i < W_KC; ++i) {
+                    f32x4 bf[C];
+#pragma unroll
+                    for (int c = 0; c < C; ++c) bf[c] = *reinterpret_cast<const f32x4*>(&AB[(c * NT + k0 + i) * 256 + lane * 4]);
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                            for (int c = 0; c < C; ++c)
+                                acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i][rt][s2], bf[c][s2], acc[rt][c], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                f32x4 tt;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float t = gpe_tanh(acc[rt][0][r]);
+                    tt[r] = t;
+                    float zk[D > 0 ? D : 1], zkk[E > 0 ? E : 1], av[C];
+#pragma unroll
+                    for (int jd = 0; jd < D; ++jd) zk[jd] = acc[rt][1 + jd][r];
+#pragma unroll
+                    for (int e = 0; e < E; ++e) zkk[e] = acc[rt][1 + D + e][r];
+                    act_from_stored<D, E>(t, zk, zkk, shift, av);
+#pragma unroll
+                    for (int c = 0; c < C; ++c) a[rt][c][r] = av[c];
+                }
+                if (store_acts) {
+                    float* sp = stored + ((((size_t)tile * (L - 1) + (j - 1)) * C) * NT + w * RT + rt) * 256 + lane * 4;
+                    *reinterpret_cast<f32x4*>(sp) = tt;
+#pragma unroll
+                    for (int c = 1; c < C; ++c) *reinterpret_cast<f32x4*>(sp + (size_t)c * NT * 256) = acc[rt][c];
+                }
+            }
+        }
+        // output layer: this wave's part of the dot products, reduced over the 4 q-lanes of a point, then over the waves
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+            float part[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) part[c] = 0.f;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(&Wo[o * H + 16 * (w * RT + rt) + 4 * q]);
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) part[c] = fmaf(wv[r], a[rt][c][r], part[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                float v = part[c];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                if (q == 0) OP[((w * NOUT + o) * C + c) * 16 + m] = v;
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < NOUT * C * 16; i += NTHR) {
+            const int pmi = i & 15, oc = i >> 4, c = oc % C, o = oc / C;
+            float v = (c == 0) ? bo[o] : 0.f;
+#pragma unroll
+            for (int ww = 0; ww < W_NW; ++ww) v += OP[((ww * NOUT + o) * C + c) * 16 + pmi];
+            const int64_t p = tile * 16 + pmi;
+            if (p < N) O[((int64_t)c * NOUT + o) * ld + p] = v;
+        }
+        // OP is rewritten only after the two barriers of the next tile's first hidden map (L >= 2)
+    }
+}
+
+// workgroup b of a launch of G*NSPLIT workgroups -> (half h, tile group g).  Workgroups are dealt round-robin over the 8 XCDs
+// (b and b+8 share one): the NSPLIT workgroups of a tile group are placed on the same XCD so that the second read of zbar_j is
+// served by that XCD's L2.  Speed only -- any mapping is correct.
+GPE_DEV void w_block_role(int b, int G, int NSPLIT, int& h, int& g) {
+    if ((G & 7) == 0) { const int xcd = b & 7, idx = b >> 3; h = idx % NSPLIT; g = (idx / NSPLIT) * 8 + xcd; }
+    else { h = b % NSPLIT; g = b / NSPLIT; }
+}
+
+// ---- reverse, output layer ---------------------------------------------------------------------------------------------------
+// gslab: [G][Ppad]; workgroup (h, g) owns the features [16*8*h, 16*8*(h+1)) of the last hidden layer (wave w: feature tile 8h+w).
+template <int H, int C, int E, int NOUT, int NSPLIT>
+__global__ __launch_bounds__(512, 2) void w_bwd_out(NetDesc nd, const float* __restrict__ theta, Pts x,
+                                                    const float* __restrict__ stored, const float* __restrict__ Ob,
+                                                    float* __restrict__ Zout, float* __restrict__ gslab, int64_t N,
+                                                    int64_t ld, int Ppad, int G) {
+    constexpr int D = C - 1 - E, NT = H / 16, NTHR = 64 * W_NW, KTL = NT / NSPLIT;
+    static_assert(KTL == W_NW, "one feature tile per wave");
+    extern __shared__ __attribute__((aligned(16))) float lds_o[];
+    float* gsm = lds_o;                                           // [NOUT][H] dW_out | [NOUT] db_out (+pad)
+    float* w0s = gsm + ((NOUT * H + NOUT + 3) & ~3);
+    const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4, w = threadIdx.x >> 6;
+    int h, g;
+    w_block_role(blockIdx.x, G, NSPLIT, h, g);
+    const int L = nd.n_lin - 1;
+    const int dim = nd.dim;
+    const float shift = nd.shift;
+    const int64_t ntiles = (N + 15) >> 4;
+    const int ktile = h * KTL + w;
+    for (int i = threadIdx.x; i < ((NOUT * H + NOUT + 3) & ~3); i += NTHR) gsm[i] = 0.f;
+    stage_layer0<H>(w0s, theta, nd, NTHR);
+    __syncthreads();
+    const float* Wo = w0s + (4 + L - 1) * H;
+    for (int64_t tile = g; tile < ntiles; tile += G) {
+        const int64_t pm = tile * 16 + m;
+        const bool valid = pm < N;
+        const int64_t pl = valid ? pm : N - 1;
+        float ob[NOUT][C];
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+            for (int c = 0; c < C; ++c) ob[o][c] = valid ? Ob[((int64_t)c * NOUT + o) * ld + pm] : 0.f;
+        f32x4 st[C];
+        if (L - 1 >= 1) {
+            const float* sp = stored + ((((size_t)tile * (L - 1) + (L - 2)) * C) * NT + ktile) * 256 + lane * 4;
+#pragma unroll
+            for (int c = 0; c < C; ++c) st[c] = *reinterpret_cast<const f32x4*>(sp + (size_t)c * NT * 256);
+        } else {
+            float xv[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) if (k < dim) xv[k] = pts_at(x, pl, dim, k);
+            layer0_st<H, C, E>(w0s, xv, ktile, q, st);
+        }
+        f32x4 wo[NOUT];
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) wo[o] = *reinterpret_cast<const f32x4*>(&Wo[o * H + 16 * ktile + 4 * q]);
+        float gwo[NOUT][4];
+        f32x4 zb[C];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float zk[D > 0 ? D : 1], zkk[E > 0 ? E : 1], a[C], ab[C], zv[C];
+#pragma unroll
+            for (int jd = 0; jd < D; ++jd) zk[jd] = st[1 + jd][r];
+#pragma unroll
+            for (int e = 0; e < E; ++e) zkk[e] = st[1 + D + e][r];
+            act_from_stored<D, E>(st[0][r], zk, zkk, shift, a);
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) {
+                float gg = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) gg = fmaf(ob[o][c], a[c], gg);
+                gwo[o][r] = gg;
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                float v = 0.f;
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) v = fmaf(wo[o][r], ob[o][c], v);
+                ab[c] = v;
+            }
+            act_adjoint<D, E>(st[0][r], zk, zkk, ab, zv);
+#pragma unroll
+            for (int c = 0; c < C; ++c) zb[c][r] = zv[c];
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            *reinterpret_cast<f32x4*>(&Zout[(((size_t)tile * C + c) * NT + ktile) * 256 + lane * 4]) = zb[c];
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) row_reduce4_add(gwo[o], &gsm[o * H + 16 * ktile], m, q);
+        if (h == 0 && w == 0) {
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) {
+                const float gbo = row_sum16(ob[o][0]);
+                if (lane == 0) atomicAdd(&gsm[NOUT * H + o], gbo);
+            }
+        }
+    }
+    __syncthreads();
+    float* slab = gslab + (size_t)g * Ppad;
+    for (int i = threadIdx.x; i < NOUT * 16 * KTL; i += NTHR) {
+        const int o = i / (16 * KTL), f = 16 * KTL * h + i % (16 * KTL);
+        slab[nd.offW[L] + o * H + f] = gsm[o * H + f];
+    }
+    if (h == 0) for (int i = threadIdx.x; i < NOUT; i += NTHR) slab[nd.offB[L] + i] = gsm[NOUT * H + i];
+}
+
+// ---- reverse, one hidden->hidden map ------------------------------------------------------------------------------------------
+// Zin = zbar_j, Zout = zbar_{j-1}: [tile][C][NT][256].  FIRST (j == 1): layer j-1 = 0 is recomputed from x, its gradients
+// (dW_0, db_0) are formed here and nothing is written to Zout.
+// LDS: gb[H] (db_j) | g0[4][H] | w0s | ZB[C][NT][256] | XT[C][8][F_TILE] (before the adjoint phase: the waves' transposition scratch)
+template <int H, int C, int E, int NSPLIT, bool FIRST>
+__global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const float* __restrict__ theta,
+                                                    const float* __restrict__ WpkT, Pts x,
+                                                    const float* __restrict__ stored, const float* __restrict__ Zin,
+                                                    float* __restrict__ Zout, float* __restrict__ gslab, int64_t N, int Ppad,
+                                                    int G) {
+    constexpr int D = C - 1 - E, NT = H / 16, NTHR = 64 * W_NW, RTZ = NT / W_NW, KTL = NT / NSPLIT;
+    static_assert(KTL == W_NW, "one layer-(j-1) feature tile per wave");
+    extern __shared__ __attribute__((aligned(16))) float lds_m[];
+    float* gb = lds_m;
+    float* g0 = gb + H;
+    float* w0s = g0 + 4 * H;
+    float* ZB = w0s + ((small_count(nd, H) + 3) & ~3);
+    float* XT = ZB + C * NT * 256;
+    const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4, w = threadIdx.x >> 6;
+    float* TT = XT + w * (C * F_TILE);
+    int h, g;
+    w_block_role(blockIdx.x, G, NSPLIT, h, g);
+    const int L = nd.n_lin - 1;
+    const int dim = nd.dim;
+    const float shift = nd.shift;
+    const int64_t ntiles = (N + 15) >> 4;
+    const int ktile = h * KTL + w;                               // this wave's feature tile of layer j-1
+    for (int i = threadIdx.x; i < 5 * H; i += NTHR) gb[i] = 0.f; // gb and g0 are contiguous
+    if constexpr (FIRST) stage_layer0<H>(w0s, theta, nd, NTHR);
+    const float* wbase = WpkT + (size_t)(j - 1) * H * H;
+    auto load_w = [&](int nt) { return *reinterpret_cast<const f32x4*>(&wbase[((ktile * NT + nt) * 64 + lane) * 4]); };
+    f32x4 dwacc[RTZ][KTL];                                       // rows 16(w RTZ + rt).., column tiles of this half
+#pragma unroll
+    for (int rt = 0; rt < RTZ; ++rt)
+#pragma unroll
+        for (int kt = 0; kt < KTL; ++kt) dwacc[rt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float dbacc[RTZ];
+#pragma unroll
+    for (int rt = 0; rt < RTZ; ++rt) dbacc[rt] = 0.f;
+    __syncthreads();
+
+    for (int64_t tile = g; tile < ntiles; tile += G) {
+        asm volatile("" : "+s"(wbase));
+        // own rows of zbar_j
+        f32x4 zf[RTZ][C];
+#pragma unroll
+        for (int rt = 0; rt < RTZ; ++rt)
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                zf[rt][c] = *reinterpret_cast<const f32x4*>(&Zin[(((size_t)tile * C + c) * NT + w * RTZ + rt) * 256 + lane * 4]);
+        // stored (t, z_k, z_L) of layer j-1, own feature tile: in flight across the barriers and the adjoint products
+        f32x4 st[C];
+        float xv[3] = {0.f, 0.f, 0.f};
+        if constexpr (FIRST) {
+            const int64_t pm = tile * 16 + m;
+            const int64_t pl = pm < N ? pm : N - 1;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) if (k < dim) xv[k] = pts_at(x, pl, dim, k);
+            layer0_st<H, C, E>(w0s, xv, ktile, q, st);
+        } else {
+            const float* sp = stored + ((((size_t)tile * (L - 1) + (j - 2)) * C) * NT + ktile) * 256 + lane * 4;
+#pragma unroll
+            for (int c = 0; c < C; ++c) st[c] = *reinterpret_cast<const f32x4*>(sp + (size_t)c * NT * 256);
+        }
+        f32x4 wn[W_KC];
+#pragma unroll
+        for (int i = 0; i < W_KC; ++i) wn[i] = load_w(i);
+        __syncthreads();                                         // previous tile: XT (products) and ZB (adjoint) are no longer read
+        f32x4 zt[RTZ][C];
+#pragma unroll
+        for (int rt = 0; rt < RTZ; ++rt) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) *reinterpret_cast<f32x4*>(&ZB[(c * NT + w * RTZ + rt) * 256 + lane * 4]) = zf[rt][c];
+            tiles_transpose<C>(zf[rt], zt[rt], TT, m, q);          // feature-on-lane copy for the weight-gradient products
+            if (h == 0) {                                        // bias gradient of map j: row sums of the value channel
+                float s = (zt[rt][0][0] + zt[rt][0][1]) + (zt[rt][0][2] + zt[rt][0][3]);
+                s += __shfl_xor(s, 16, 64);
+                s += __shfl_xor(s, 32, 64);
+                dbacc[rt] += s;
+            }
+        }
+        __syncthreads();                                         // ZB complete; the scratch (= XT) may be overwritten from here on
+        // abar (own feature tile of layer j-1) = sum_nt W_j^T[ktile, nt] zbar_j[nt] : C independent accumulator chains
+        f32x4 acc[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int n0 = 0; n0 < NT; n0 += W_KC) {
+            f32x4 wv[W_KC];
+#pragma unroll
+            for (int i = 0; i < W_KC; ++i) wv[i] = wn[i];
+            if (n0 + W_KC < NT) {
+#pragma unroll
+                for (int i = 0; i < W_KC; ++i) wn[i] = load_w(n0 + W_KC + i);
+            }
+#pragma unroll
+            for (int i = 0; i < W_KC; ++i) {
+                f32x4 bf[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) bf[c] = *reinterpret_cast<const f32x4*>(&ZB[(c * NT + n0 + i) * 256 + lane * 4]);
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                    for (int c = 0; c < C; ++c)
+                        acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i][s2], bf[c][s2], acc[c], 0, 0, 0);
+            }
+        }
+        // recompute X of layer j-1 (own tile), activation adjoint -> zbar_{j-1}
+        f32x4 xa[C], zb[C];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float zk[D > 0 ? D : 1], zkk[E > 0 ? E : 1], a[C], ab[C], zv[C];
+#pragma unroll
+            for (int jd = 0; jd < D; ++jd) zk[jd] = st[1 + jd][r];
+#pragma unroll
+            for (int e = 0; e < E; ++e) zkk[e] = st[1 + D + e][r];
+            act_from_stored<D, E>(st[0][r], zk, zkk, shift, a);
+#pragma unroll
+            for (int c = 0; c < C; ++c) { xa[c][r] = a[c]; ab[c] = acc[c][r]; }
+            act_adjoint<D, E>(st[0][r], zk, zkk, ab, zv);
+#pragma unroll
+            for (int c = 0; c < C; ++c) zb[c][r] = zv[c];
+        }
+        if constexpr (!FIRST) {
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                *reinterpret_cast<f32x4*>(&Zout[(((size_t)tile * C + c) * NT + ktile) * 256 + lane * 4]) = zb[c];
+        } else {      // linear map 0: g0[k][n] (k < dim: dW0[n][k]; k = 3: db0[n])
+            const float z0[4] = {zb[0][0], zb[0][1], zb[0][2], zb[0][3]};
+            row_reduce4_add(z0, &g0[3 * H + 16 * ktile], m, q);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (k < D || (D == 0 && k < dim)) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = zb[0][r] * xv[k];
+                        if constexpr (C > 1) { if (k < D) v[r] += zb[(1 + k) < C ? (1 + k) : 0][r]; }
+                    }
+                    row_reduce4_add(v, &g0[k * H + 16 * ktile], m, q);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) XT[(c * KTL + w) * F_TILE + (4 * q + r) * F_PITCH + m] = xa[c][r];
+        __syncthreads();
+        // dW_j[own rows][columns of this half] += Zbar^T X : RTZ * 4 independent accumulator chains per chunk
+#pragma unroll
+        for (int k0 = 0; k0 < KTL; k0 += 4)
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                f32x4 xf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    xf[i] = *reinterpret_cast<const f32x4*>(&XT[(c * KTL + k0 + i) * F_TILE + m * F_PITCH + 4 * q]);
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int rt = 0; rt < RTZ; ++rt)
+                            dwacc[rt][k0 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(zt[rt][c][s2], xf[i][s2], dwacc[rt][k0 + i], 0, 0, 0);
+            }
+    }
+    // ---- slab: this workgroup's block of dW_j, db_j (h == 0), layer-0 gradients of its features (FIRST) ------------------------
+    float* slab = gslab + (size_t)g * Ppad;
+#pragma unroll
+    for (int rt = 0; rt < RTZ; ++rt)
+#pragma unroll
+        for (int kt = 0; kt < KTL; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                slab[nd.offW[j] + (16 * (w * RTZ + rt) + 4 * q + r) * H + 16 * (h * KTL + kt) + m] = dwacc[rt][kt][r];
+    if (h == 0 && q == 0) {
+#pragma unroll
+        for (int rt = 0; rt < RTZ; ++rt) slab[nd.offB[j] + 16 * (w * RTZ + rt) + m] = dbacc[rt];
+    }
+    if constexpr (FIRST) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 4 * 16 * KTL; i += NTHR) {
+            const int k = i / (16 * KTL), n = 16 * KTL * h + i % (16 * KTL);
+            if (k == 3) slab[nd.offB[0] + n] = g0[3 * H + n];
+            else if (k < dim) slab[nd.offW[0] + n * dim + k] = g0[k * H + n];
+        }
+    }
+}

@@ -1,0 +1,103 @@
+// gpe_wide.hip -- launchers of the wide kernel set (gpe_wide.h).  gfx950 only.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+
+#include "gpe_wide.h"
+#include "gpe_wide_api.h"
+
+static size_t small4(const NetDesc& nd, int H) { return (size_t)(((4 + (nd.n_lin - 2) + nd.n_out) * H + 4 + 3) & ~3); }
+
+bool wide_shape_ok(int H) { return H == 128 || H == 256; }
+
+int wide_groups(int H, int64_t N, int num_cu) {
+    const int nsplit = H / 128;
+    int64_t g = std::min<int64_t>((N + 15) / 16, num_cu / nsplit);
+    if (g >= 8) g &= ~(int64_t)7;          // multiples of 8: the halves of a tile group land on one XCD
+    return (int)std::max<int64_t>(g, 1);
+}
+
+#ifdef GPE_FAST_BUILD
+#define W_FOR_SHAPES(X) X(256, 1, 0) X(256, 5, 1)
+#define W_FOR_FWD_ONLY(X)
+#define W_NOUT2 0
+#else
+#define W_FOR_SHAPES(X) X(256, 1, 0) X(256, 3, 1) X(256, 4, 1) X(256, 5, 1) X(128, 1, 0) X(128, 3, 1) X(128, 4, 1) X(128, 5, 1)
+#define W_FOR_FWD_ONLY(X) X(256, 5, 2) X(256, 7, 3) X(128, 5, 2) X(128, 7, 3)
+#define W_NOUT2 1
+#endif
+
+void wide_init() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    const int lds = 160 * 1024;
+#define ATTR_F(HH, CC, EE)                                                                                               \
+    (void)hipFuncSetAttribute((const void*)w_forward<HH, CC, EE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);   \
+    if (W_NOUT2) (void)hipFuncSetAttribute((const void*)w_forward<HH, CC, EE, W_NOUT2 ? 2 : 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+#define ATTR_B(HH, CC, EE)                                                                                                                \
+    (void)hipFuncSetAttribute((const void*)w_bwd_map<HH, CC, EE, HH / 128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);      \
+    (void)hipFuncSetAttribute((const void*)w_bwd_map<HH, CC, EE, HH / 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);       \
+    (void)hipFuncSetAttribute((const void*)w_bwd_out<HH, CC, EE, 1, HH / 128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);          \
+    if (W_NOUT2) (void)hipFuncSetAttribute((const void*)w_bwd_out<HH, CC, EE, W_NOUT2 ? 2 : 1, HH / 128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    W_FOR_SHAPES(ATTR_F) W_FOR_FWD_ONLY(ATTR_F) W_FOR_SHAPES(ATTR_B)
+#undef ATTR_F
+#undef ATTR_B
+}
+
+template <int HH, int CC, int EE>
+static void launch_fwd(const WideCall& a, int store) {
+    const int NT = HH / 16;
+    const int64_t ntiles = (a.N + 15) / 16;
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ntiles, a.num_cu));
+    const size_t lds = (small4(a.nd, HH) + (size_t)CC * NT * 256 + (size_t)W_NW * a.nd.n_out * CC * 16) * sizeof(float);
+    if (a.nd.n_out == 1)
+        hipLaunchKernelGGL((w_forward<HH, CC, EE, 1>), dim3(grid), dim3(512), lds, a.stream, a.nd, a.theta, a.Wpk, a.pts, a.stored, a.O,
+                           a.N, a.ld, store);
+    else
+        hipLaunchKernelGGL((w_forward<HH, CC, EE, W_NOUT2 ? 2 : 1>), dim3(grid), dim3(512), lds, a.stream, a.nd, a.theta, a.Wpk, a.pts,
+                           a.stored, a.O, a.N, a.ld, store);
+}
+
+int wide_forward(const WideCall& a, int store) {
+    if (!W_NOUT2 && a.nd.n_out != 1) return -1;
+#define CASE_F(HH, CC, EE) if (a.H == HH && a.C == CC && a.E == EE) { launch_fwd<HH, CC, EE>(a, store); return (int)hipGetLastError(); }
+    W_FOR_SHAPES(CASE_F) W_FOR_FWD_ONLY(CASE_F)
+#undef CASE_F
+    return -1;
+}
+
+template <int HH, int CC, int EE>
+static void launch_bwd(const WideCall& a) {
+    constexpr int NS = HH / 128, NT = HH / 16;
+    const int G = wide_groups(HH, a.N, a.num_cu);
+    const unsigned grid = (unsigned)(G * NS);
+    const int L = a.nd.n_lin - 1;
+    const int no = a.nd.n_out;
+    const size_t lds_o = ((size_t)((no * HH + no + 3) & ~3) + small4(a.nd, HH)) * sizeof(float);
+    const size_t lds_m = ((size_t)5 * HH + small4(a.nd, HH) + (size_t)CC * NT * 256 + (size_t)CC * W_NW * F_TILE) * sizeof(float);
+    float* zcur = a.Z0;
+    float* znext = a.Z1;
+    if (no == 1)
+        hipLaunchKernelGGL((w_bwd_out<HH, CC, EE, 1, NS>), dim3(grid), dim3(512), lds_o, a.stream, a.nd, a.theta, a.pts, a.stored, a.Ob,
+                           zcur, a.gslab, a.N, a.ld, a.Ppad, G);
+    else
+        hipLaunchKernelGGL((w_bwd_out<HH, CC, EE, W_NOUT2 ? 2 : 1, NS>), dim3(grid), dim3(512), lds_o, a.stream, a.nd, a.theta, a.pts,
+                           a.stored, a.Ob, zcur, a.gslab, a.N, a.ld, a.Ppad, G);
+    for (int j = L - 1; j >= 1; --j) {
+        if (j > 1)
+            hipLaunchKernelGGL((w_bwd_map<HH, CC, EE, NS, false>), dim3(grid), dim3(512), lds_m, a.stream, a.nd, j, a.theta, a.WpkT, a.pts,
+                               a.stored, zcur, znext, a.gslab, a.N, a.Ppad, G);
+        else
+            hipLaunchKernelGGL((w_bwd_map<HH, CC, EE, NS, true>), dim3(grid), dim3(512), lds_m, a.stream, a.nd, j, a.theta, a.WpkT, a.pts,
+                               a.stored, zcur, znext, a.gslab, a.N, a.Ppad, G);
+        std::swap(zcur, znext);
+    }
+}
+
+int wide_backward(const WideCall& a) {
+    if (!W_NOUT2 && a.nd.n_out != 1) return -1;
+#define CASE_B(HH, CC, EE) if (a.H == HH && a.C == CC && a.E == EE) { launch_bwd<HH, CC, EE>(a); return (int)hipGetLastError(); }
+    W_FOR_SHAPES(CASE_B)
+#undef CASE_B
+    return -1;
+}
