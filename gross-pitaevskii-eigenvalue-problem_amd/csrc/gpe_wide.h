@@ -26,7 +26,8 @@
 #include "gpe_mfma_util.h"
 
 #define W_NW 8            // waves per workgroup
-#define W_KC 4            // K tiles per streamed weight chunk
+#define W_KC 4            // K tiles per streamed weight chunk (forward)
+#define W_KCB 2           // ... in the reverse map kernel (register budget: 256 with the 64-register gradient block)
 
 template <int H, int C>
 __host__ __device__ constexpr int w_fwd_lds_floats(int small, int nout) { return small + C * (H / 16) * 256 + W_NW * nout * C * 16; }
@@ -51,10 +52,10 @@ __global__ __launch_bounds__(512, 2) void w_forward(NetDesc nd, const float* __r
     __syncthreads();
     const float* Wo = w0s + (4 + L - 1) * H;
     const float* bo = w0s + (4 + L - 1 + NOUT) * H;
-    const float* wbase = Wpk;
+    int wofs = 0;                                               // opaque zero: keeps the (tile-invariant) weight loads inside the loop
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        asm volatile("" : "+s"(wbase));                        // keep the (tile-invariant) weight loads inside the loop
+        asm volatile("" : "+s"(wofs));                         // (an opaque OFFSET, not an opaque pointer: the loads stay global_load)
         const int64_t pm = tile * 16 + m;
         const bool valid = pm < N;
         const int64_t pl = valid ? pm : N - 1;
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(512, 2) void w_forward(NetDesc nd, const float* __r
             }
         }
         for (int j = 1; j < L; ++j) {
-            const float* Wp = wbase + (size_t)(j - 1) * H * H;
+            const float* Wp = Wpk + (size_t)(j - 1) * H * H + wofs;
             auto load_w = [&](int rt, int kt) {
                 return *reinterpret_cast<const f32x4*>(&Wp[(((w * RT + rt) * NT + kt) * 64 + lane) * 4]);
             };
@@ -113,6 +114,7 @@ __global__ __launch_bounds__(512, 2) void w_forward(NetDesc nd, const float* __r
                     for (int i = 0; i < W_KC; ++i)
 #pragma unroll
                         for (int rt = 0; rt < RT; ++rt) wn[i][rt] = load_w(rt, k0 + W_KC + i);
+                    __builtin_amdgcn_sched_barrier(0);          // the next chunk's loads are issued BEFORE this chunk's products
                 }
 #pragma unroll
                 for (int i = 0; i < W_KC; ++i) {
@@ -321,8 +323,9 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
     const int ktile = h * KTL + w;                               // this wave's feature tile of layer j-1
     for (int i = threadIdx.x; i < 5 * H; i += NTHR) gb[i] = 0.f; // gb and g0 are contiguous
     if constexpr (FIRST) stage_layer0<H>(w0s, theta, nd, NTHR);
-    const float* wbase = WpkT + (size_t)(j - 1) * H * H;
-    auto load_w = [&](int nt) { return *reinterpret_cast<const f32x4*>(&wbase[((ktile * NT + nt) * 64 + lane) * 4]); };
+    const float* wmap = WpkT + (size_t)(j - 1) * H * H;
+    int wofs = 0;                                               // opaque zero: keeps the weight loads inside the tile loop
+    auto load_w = [&](int nt) { return *reinterpret_cast<const f32x4*>(&wmap[wofs + ((ktile * NT + nt) * 64 + lane) * 4]); };
     f32x4 dwacc[RTZ][KTL];                                       // rows 16(w RTZ + rt).., column tiles of this half
 #pragma unroll
     for (int rt = 0; rt < RTZ; ++rt)
@@ -333,32 +336,40 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
     for (int rt = 0; rt < RTZ; ++rt) dbacc[rt] = 0.f;
     __syncthreads();
 
-    for (int64_t tile = g; tile < ntiles; tile += G) {
-        asm volatile("" : "+s"(wbase));
-        // own rows of zbar_j
-        f32x4 zf[RTZ][C];
+    // The wave's rows of zbar_j (HBM, needed first thing in a tile) are requested one tile AHEAD, before the weight-gradient
+    // products of the previous tile: their latency hides behind ~10 000 cycles of MFMAs instead of stalling all eight waves at
+    // the top of every tile.  (The stored activations and the first weight chunk are needed only after the barriers / the
+    // adjoint products, so they are requested at the top of their own tile.)
+    f32x4 zf[RTZ][C];
+    float xv[3] = {0.f, 0.f, 0.f};
+    auto issue_loads = [&](int64_t t) {
 #pragma unroll
         for (int rt = 0; rt < RTZ; ++rt)
 #pragma unroll
             for (int c = 0; c < C; ++c)
-                zf[rt][c] = *reinterpret_cast<const f32x4*>(&Zin[(((size_t)tile * C + c) * NT + w * RTZ + rt) * 256 + lane * 4]);
-        // stored (t, z_k, z_L) of layer j-1, own feature tile: in flight across the barriers and the adjoint products
-        f32x4 st[C];
-        float xv[3] = {0.f, 0.f, 0.f};
+                zf[rt][c] = *reinterpret_cast<const f32x4*>(&Zin[(((size_t)t * C + c) * NT + w * RTZ + rt) * 256 + lane * 4]);
         if constexpr (FIRST) {
-            const int64_t pm = tile * 16 + m;
+            const int64_t pm = t * 16 + m;
             const int64_t pl = pm < N ? pm : N - 1;
 #pragma unroll
             for (int k = 0; k < 3; ++k) if (k < dim) xv[k] = pts_at(x, pl, dim, k);
-            layer0_st<H, C, E>(w0s, xv, ktile, q, st);
-        } else {
+        }
+    };
+    if (g < ntiles) issue_loads(g);
+
+    for (int64_t tile = g; tile < ntiles; tile += G) {
+        asm volatile("" : "+s"(wofs));
+        f32x4 st[C];
+        if constexpr (FIRST) layer0_st<H, C, E>(w0s, xv, ktile, q, st);
+        else {
             const float* sp = stored + ((((size_t)tile * (L - 1) + (j - 2)) * C) * NT + ktile) * 256 + lane * 4;
 #pragma unroll
             for (int c = 0; c < C; ++c) st[c] = *reinterpret_cast<const f32x4*>(sp + (size_t)c * NT * 256);
         }
-        f32x4 wn[W_KC];
+        const float xk[3] = {xv[0], xv[1], xv[2]};             // this tile's coordinates (xv is overwritten by the prefetch)
+        f32x4 wn[W_KCB];
 #pragma unroll
-        for (int i = 0; i < W_KC; ++i) wn[i] = load_w(i);
+        for (int i = 0; i < W_KCB; ++i) wn[i] = load_w(i);
         __syncthreads();                                         // previous tile: XT (products) and ZB (adjoint) are no longer read
         f32x4 zt[RTZ][C];
 #pragma unroll
@@ -379,16 +390,17 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
 #pragma unroll
         for (int c = 0; c < C; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int n0 = 0; n0 < NT; n0 += W_KC) {
-            f32x4 wv[W_KC];
+        for (int n0 = 0; n0 < NT; n0 += W_KCB) {
+            f32x4 wv[W_KCB];
 #pragma unroll
-            for (int i = 0; i < W_KC; ++i) wv[i] = wn[i];
-            if (n0 + W_KC < NT) {
+            for (int i = 0; i < W_KCB; ++i) wv[i] = wn[i];
+            if (n0 + W_KCB < NT) {
 #pragma unroll
-                for (int i = 0; i < W_KC; ++i) wn[i] = load_w(n0 + W_KC + i);
+                for (int i = 0; i < W_KCB; ++i) wn[i] = load_w(n0 + W_KCB + i);
+                __builtin_amdgcn_sched_barrier(0);              // issued before this chunk's products
             }
 #pragma unroll
-            for (int i = 0; i < W_KC; ++i) {
+            for (int i = 0; i < W_KCB; ++i) {
                 f32x4 bf[C];
 #pragma unroll
                 for (int c = 0; c < C; ++c) bf[c] = *reinterpret_cast<const f32x4*>(&ZB[(c * NT + n0 + i) * 256 + lane * 4]);
@@ -428,7 +440,7 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
                     float v[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        v[r] = zb[0][r] * xv[k];
+                        v[r] = zb[0][r] * xk[k];
                         if constexpr (C > 1) { if (k < D) v[r] += zb[(1 + k) < C ? (1 + k) : 0][r]; }
                     }
                     row_reduce4_add(v, &g0[k * H + 16 * ktile], m, q);
@@ -439,6 +451,8 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
         for (int c = 0; c < C; ++c)
 #pragma unroll
             for (int r = 0; r < 4; ++r) XT[(c * KTL + w) * F_TILE + (4 * q + r) * F_PITCH + m] = xa[c][r];
+        if (tile + G < ntiles) issue_loads(tile + G);            // next tile's loads: in flight behind the products below
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         // dW_j[own rows][columns of this half] += Zbar^T X : RTZ * 4 independent accumulator chains per chunk
 #pragma unroll

@@ -108,7 +108,7 @@ def _scale(kw):
 
 
 # shapes whose whole-network (fused) kernel is not built yet: they run on the generic layer-wise set only
-PENDING_FUSED = {"3d_256x6_cfg5_N300", "3d_256x6_cfg5_N4099", "3d_128x6_N300", "3d_128x3_N1000", "2d_256x3", "1d_256x2"}
+PENDING_FUSED = set()
 
 
 def _case_params():
@@ -336,7 +336,7 @@ def test_error_behaviour():
     with pytest.raises(ValueError):
         Engine(GPEConfig(layers=[4, 32, 32, 1]))
     with pytest.raises(ValueError):
-        Engine(GPEConfig(layers=[3, 128, 128, 1], path=gpe_pinn.PATH_FUSED))          # wide fused variant is dim <= 2
+        Engine(GPEConfig(layers=[2, 96, 96, 1], path=gpe_pinn.PATH_FUSED))            # no whole-network kernel for this width
     eng = Engine(GPEConfig(layers=[1, 32, 32, 1]))
     with pytest.raises(gpe_pinn.GPEError) as ei:
         eng.step()
