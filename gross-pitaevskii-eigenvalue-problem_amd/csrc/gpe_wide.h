@@ -25,6 +25,29 @@
 #pragma once
 #include "gpe_mfma_util.h"
 
+// ---- diagnostic build only (-DGPE_STAMP): per-phase cycle shares via s_memtime (wave 0 of every workgroup) -------------------
+#ifdef GPE_STAMP
+__device__ unsigned long long w_stamps[16];
+GPE_DEV unsigned long long w_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+__device__ unsigned long long w_trace[2][8][16];     // absolute stamps of one iteration of workgroup 0: [kernel][wave][stamp]
+#define WSTAMP(i) do { unsigned long long _t = w_now(); st_acc[(i) & 7] += _t - st_last; st_last = _t;               \
+                       if (blockIdx.x == 0 && st_iter == 4 && (threadIdx.x & 63) == 0) w_trace[W_TRACE_K][threadIdx.x >> 6][i] = _t; } while (0)
+#define WSTAMP_INIT unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_last = w_now(); int st_iter = 0
+#define WSTAMP_ITER (++st_iter)
+#define WSTAMP_FLUSH(base) do { if (threadIdx.x == 0) for (int _i = 0; _i < 8; ++_i) atomicAdd(&w_stamps[(base) + _i], st_acc[_i]); } while (0)
+#else
+#define WSTAMP(i) do { } while (0)
+#define WSTAMP_INIT do { } while (0)
+#define WSTAMP_FLUSH(base) do { } while (0)
+#define WSTAMP_ITER do { } while (0)
+#endif
+
 #define W_NW 8            // waves per workgroup
 #define W_KC 4            // K tiles per streamed weight chunk (forward)
 #define W_KCB 2           // ... in the reverse map kernel (register budget: 256 with the 64-register gradient block)
@@ -33,6 +56,7 @@ template <int H, int C>
 __host__ __device__ constexpr int w_fwd_lds_floats(int small, int nout) { return small + C * (H / 16) * 256 + W_NW * nout * C * 16; }
 
 // ---- forward ---------------------------------------------------------------------------------------------------------------
+#define W_TRACE_K 0
 template <int H, int C, int E, int NOUT>
 __global__ __launch_bounds__(512, 2) void w_forward(NetDesc nd, const float* __restrict__ theta,
                                                     const float* __restrict__ Wpk, Pts x, float* __restrict__ stored,
@@ -53,6 +77,8 @@ __global__ __launch_bounds__(512, 2) void w_forward(NetDesc nd, const float* __r
     const float* Wo = w0s + (4 + L - 1) * H;
     const float* bo = w0s + (4 + L - 1 + NOUT) * H;
     int wofs = 0;                                               // opaque zero: keeps the (tile-invariant) weight loads inside the loop
+    WSTAMP_INIT;
+    const bool hi_even = w < 4;
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         asm volatile("" : "+s"(wofs));                         // (an opaque OFFSET, not an opaque pointer: the loads stay global_load)
@@ -80,6 +106,7 @@ __global__ __launch_bounds__(512, 2) void w_forward(NetDesc nd, const float* __r
             }
         }
         for (int j = 1; j < L; ++j) {
+            WSTAMP_ITER;
             const float* Wp = Wpk + (size_t)(j - 1) * H * H + wofs;
             auto load_w = [&](int rt, int kt) {
                 return *reinterpret_cast<const f32x4*>(&Wp[(((w * RT + rt) * NT + kt) * 64 + lane) * 4]);
@@ -89,12 +116,15 @@ __global__ __launch_bounds__(512, 2) void w_forward(NetDesc nd, const float* __r
             for (int i = 0; i < W_KC; ++i)
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) wn[i][rt] = load_w(rt, i);      // first chunk: in flight across the barriers
+            WSTAMP(0);
             __syncthreads();                                    // every wave is done reading AB (previous layer / tile)
+            WSTAMP(1);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                 for (int c = 0; c < C; ++c) *reinterpret_cast<f32x4*>(&AB[(c * NT + w * RT + rt) * 256 + lane * 4]) = a[rt][c];
             __syncthreads();
+            WSTAMP(2);
             f32x4 acc[RT][C];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
@@ -118,6 +148,9 @@ __global__ __launch_bounds__(512, 2) void w_forward(NetDesc nd, const float* __r
                 }
 #pragma unroll
                 for (int i = 0; i < W_KC; ++i) {
+                    // the two waves of a SIMD (w, w + 4) take turns at the matrix pipe, one K tile each: under plain age arbitration
+                    // the older wave runs its whole loop first and each wave's operand waits are exposed (measured: -6 %)
+                    if ((((k0 + i) & 1) == 0) == hi_even) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
                     f32x4 bf[C];
 #pragma unroll
                     for (int c = 0; c < C; ++c) bf[c] = *reinterpret_cast<const f32x4*>(&AB[(c * NT + k0 + i) * 256 + lane * 4]);
@@ -130,6 +163,8 @@ __global__ __launch_bounds__(512, 2) void w_forward(NetDesc nd, const float* __r
                                 acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i][rt][s2], bf[c][s2], acc[rt][c], 0, 0, 0);
                 }
             }
+            __builtin_amdgcn_s_setprio(0);
+            WSTAMP(3);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
                 f32x4 tt;
@@ -187,6 +222,7 @@ __global__ __launch_bounds__(512, 2) void w_forward(NetDesc nd, const float* __r
         }
         // OP is rewritten only after the two barriers of the next tile's first hidden map (L >= 2)
     }
+    WSTAMP_FLUSH(0);
 }
 
 // workgroup b of a launch of G*NSPLIT workgroups -> (half h, tile group g).  Workgroups are dealt round-robin over the 8 XCDs
@@ -294,22 +330,29 @@ __global__ __launch_bounds__(512, 2) void w_bwd_out(NetDesc nd, const float* __r
     if (h == 0) for (int i = threadIdx.x; i < NOUT; i += NTHR) slab[nd.offB[L] + i] = gsm[NOUT * H + i];
 }
 
+#undef W_TRACE_K
+#define W_TRACE_K 1
 // ---- reverse, one hidden->hidden map ------------------------------------------------------------------------------------------
 // Zin = zbar_j, Zout = zbar_{j-1}: [tile][C][NT][256].  FIRST (j == 1): layer j-1 = 0 is recomputed from x, its gradients
 // (dW_0, db_0) are formed here and nothing is written to Zout.
 // LDS: gb[H] (db_j) | g0[4][H] | w0s | ZB[C][NT][256] | XT[C][8][F_TILE] (before the adjoint phase: the waves' transposition scratch)
-template <int H, int C, int E, int NSPLIT, bool FIRST>
+// TOP = n_out (1 or 2) for the launch of the topmost map j = L-1, 0 otherwise: there zbar_j is not read from HBM but formed
+// from the seeds Ob and the stored activations of the last hidden layer (what w_bwd_out does as a kernel of its own), and
+// dW_out / db_out are accumulated here -- one launch and one HBM round trip of the adjoint jets fewer.
+template <int H, int C, int E, int NSPLIT, bool FIRST, int TOP>
 __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const float* __restrict__ theta,
                                                     const float* __restrict__ WpkT, Pts x,
                                                     const float* __restrict__ stored, const float* __restrict__ Zin,
                                                     float* __restrict__ Zout, float* __restrict__ gslab, int64_t N, int Ppad,
-                                                    int G) {
+                                                    int G, const float* __restrict__ Ob, int64_t ld) {
     constexpr int D = C - 1 - E, NT = H / 16, NTHR = 64 * W_NW, RTZ = NT / W_NW, KTL = NT / NSPLIT;
+    constexpr int NO = TOP > 0 ? TOP : 1;
     static_assert(KTL == W_NW, "one layer-(j-1) feature tile per wave");
     extern __shared__ __attribute__((aligned(16))) float lds_m[];
     float* gb = lds_m;
     float* g0 = gb + H;
-    float* w0s = g0 + 4 * H;
+    float* go = g0 + 4 * H;                                      // [2][H] dW_out | [4] db_out (TOP)
+    float* w0s = go + 2 * H + 4;
     float* ZB = w0s + ((small_count(nd, H) + 3) & ~3);
     float* XT = ZB + C * NT * 256;
     const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4, w = threadIdx.x >> 6;
@@ -321,8 +364,9 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
     const float shift = nd.shift;
     const int64_t ntiles = (N + 15) >> 4;
     const int ktile = h * KTL + w;                               // this wave's feature tile of layer j-1
-    for (int i = threadIdx.x; i < 5 * H; i += NTHR) gb[i] = 0.f; // gb and g0 are contiguous
-    if constexpr (FIRST) stage_layer0<H>(w0s, theta, nd, NTHR);
+    for (int i = threadIdx.x; i < 7 * H + 4; i += NTHR) gb[i] = 0.f; // gb, g0 and go are contiguous
+    if constexpr (FIRST || TOP > 0) stage_layer0<H>(w0s, theta, nd, NTHR);
+    const float* Wo = w0s + (4 + L - 1) * H;
     const float* wmap = WpkT + (size_t)(j - 1) * H * H;
     int wofs = 0;                                               // opaque zero: keeps the weight loads inside the tile loop
     auto load_w = [&](int nt) { return *reinterpret_cast<const f32x4*>(&wmap[wofs + ((ktile * NT + nt) * 64 + lane) * 4]); };
@@ -342,12 +386,27 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
     // adjoint products, so they are requested at the top of their own tile.)
     f32x4 zf[RTZ][C];
     float xv[3] = {0.f, 0.f, 0.f};
+    float obv[NO][C];                                            // TOP: the seeds of this lane's point
     auto issue_loads = [&](int64_t t) {
+        if constexpr (TOP > 0) {                                 // stored (t, z_k, z_L) of layer j = L-1, own rows; converted at the tile top
+#pragma unroll
+            for (int rt = 0; rt < RTZ; ++rt)
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    zf[rt][c] = *reinterpret_cast<const f32x4*>(
+                        &stored[(((((size_t)t * (L - 1)) + (j - 1)) * C + c) * NT + w * RTZ + rt) * 256 + lane * 4]);
+            const int64_t pm = t * 16 + m;
+#pragma unroll
+            for (int o = 0; o < NO; ++o)
+#pragma unroll
+                for (int c = 0; c < C; ++c) obv[o][c] = pm < N ? Ob[((int64_t)c * NO + o) * ld + pm] : 0.f;
+        } else {
 #pragma unroll
         for (int rt = 0; rt < RTZ; ++rt)
 #pragma unroll
             for (int c = 0; c < C; ++c)
                 zf[rt][c] = *reinterpret_cast<const f32x4*>(&Zin[(((size_t)t * C + c) * NT + w * RTZ + rt) * 256 + lane * 4]);
+        }
         if constexpr (FIRST) {
             const int64_t pm = t * 16 + m;
             const int64_t pl = pm < N ? pm : N - 1;
@@ -356,8 +415,10 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
         }
     };
     if (g < ntiles) issue_loads(g);
+    WSTAMP_INIT;
 
     for (int64_t tile = g; tile < ntiles; tile += G) {
+        WSTAMP_ITER;
         asm volatile("" : "+s"(wofs));
         f32x4 st[C];
         if constexpr (FIRST) layer0_st<H, C, E>(w0s, xv, ktile, q, st);
@@ -370,7 +431,56 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
         f32x4 wn[W_KCB];
 #pragma unroll
         for (int i = 0; i < W_KCB; ++i) wn[i] = load_w(i);
+        if constexpr (TOP > 0) {                                 // output layer: dW_out, db_out, zbar_{L-1} = act-adjoint(W_out^T Ob), own rows
+#pragma unroll
+            for (int rt = 0; rt < RTZ; ++rt) {
+                f32x4 wo[NO];
+#pragma unroll
+                for (int o = 0; o < NO; ++o) wo[o] = *reinterpret_cast<const f32x4*>(&Wo[o * H + 16 * (w * RTZ + rt) + 4 * q]);
+                float gwo[NO][4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float zk[D > 0 ? D : 1], zkk[E > 0 ? E : 1], a[C], ab[C], zv[C];
+#pragma unroll
+                    for (int jd = 0; jd < D; ++jd) zk[jd] = zf[rt][1 + jd][r];
+#pragma unroll
+                    for (int e = 0; e < E; ++e) zkk[e] = zf[rt][1 + D + e][r];
+                    const float tt = zf[rt][0][r];
+                    act_from_stored<D, E>(tt, zk, zkk, shift, a);
+#pragma unroll
+                    for (int o = 0; o < NO; ++o) {
+                        float gg = 0.f;
+#pragma unroll
+                        for (int c = 0; c < C; ++c) gg = fmaf(obv[o][c], a[c], gg);
+                        gwo[o][r] = gg;
+                    }
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        float v = 0.f;
+#pragma unroll
+                        for (int o = 0; o < NO; ++o) v = fmaf(wo[o][r], obv[o][c], v);
+                        ab[c] = v;
+                    }
+                    act_adjoint<D, E>(tt, zk, zkk, ab, zv);
+#pragma unroll
+                    for (int c = 0; c < C; ++c) zf[rt][c][r] = zv[c];
+                }
+                if (h == 0) {
+#pragma unroll
+                    for (int o = 0; o < NO; ++o) row_reduce4_add(gwo[o], &go[o * H + 16 * (w * RTZ + rt)], m, q);
+                }
+            }
+            if (h == 0 && w == 0) {
+#pragma unroll
+                for (int o = 0; o < NO; ++o) {
+                    const float gbo = row_sum16(obv[o][0]);
+                    if (lane == 0) atomicAdd(&go[2 * H + o], gbo);
+                }
+            }
+        }
+        WSTAMP(0);
         __syncthreads();                                         // previous tile: XT (products) and ZB (adjoint) are no longer read
+        WSTAMP(1);
         f32x4 zt[RTZ][C];
 #pragma unroll
         for (int rt = 0; rt < RTZ; ++rt) {
@@ -384,7 +494,9 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
                 dbacc[rt] += s;
             }
         }
+        WSTAMP(2);
         __syncthreads();                                         // ZB complete; the scratch (= XT) may be overwritten from here on
+        WSTAMP(3);
         // abar (own feature tile of layer j-1) = sum_nt W_j^T[ktile, nt] zbar_j[nt] : C independent accumulator chains
         f32x4 acc[C];
 #pragma unroll
@@ -411,6 +523,7 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
                         acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i][s2], bf[c][s2], acc[c], 0, 0, 0);
             }
         }
+        WSTAMP(4);
         // recompute X of layer j-1 (own tile), activation adjoint -> zbar_{j-1}
         f32x4 xa[C], zb[C];
 #pragma unroll
@@ -453,7 +566,9 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
             for (int r = 0; r < 4; ++r) XT[(c * KTL + w) * F_TILE + (4 * q + r) * F_PITCH + m] = xa[c][r];
         if (tile + G < ntiles) issue_loads(tile + G);            // next tile's loads: in flight behind the products below
         __builtin_amdgcn_sched_barrier(0);
+        WSTAMP(5);
         __syncthreads();
+        WSTAMP(6);
         // dW_j[own rows][columns of this half] += Zbar^T X : RTZ * 4 independent accumulator chains per chunk
 #pragma unroll
         for (int k0 = 0; k0 < KTL; k0 += 4)
@@ -471,7 +586,9 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
                         for (int rt = 0; rt < RTZ; ++rt)
                             dwacc[rt][k0 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(zt[rt][c][s2], xf[i][s2], dwacc[rt][k0 + i], 0, 0, 0);
             }
+        WSTAMP(7);
     }
+    WSTAMP_FLUSH(8);
     // ---- slab: this workgroup's block of dW_j, db_j (h == 0), layer-0 gradients of its features (FIRST) ------------------------
     float* slab = gslab + (size_t)g * Ppad;
 #pragma unroll
@@ -485,12 +602,18 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
 #pragma unroll
         for (int rt = 0; rt < RTZ; ++rt) slab[nd.offB[j] + 16 * (w * RTZ + rt) + m] = dbacc[rt];
     }
+    if constexpr (FIRST || TOP > 0) __syncthreads();
     if constexpr (FIRST) {
-        __syncthreads();
         for (int i = threadIdx.x; i < 4 * 16 * KTL; i += NTHR) {
             const int k = i / (16 * KTL), n = 16 * KTL * h + i % (16 * KTL);
             if (k == 3) slab[nd.offB[0] + n] = g0[3 * H + n];
             else if (k < dim) slab[nd.offW[0] + n * dim + k] = g0[k * H + n];
+        }
+    }
+    if constexpr (TOP > 0) {
+        if (h == 0) {
+            for (int i = threadIdx.x; i < NO * H; i += NTHR) slab[nd.offW[L] + i] = go[i];
+            for (int i = threadIdx.x; i < NO; i += NTHR) slab[nd.offB[L] + i] = go[2 * H + i];
         }
     }
 }

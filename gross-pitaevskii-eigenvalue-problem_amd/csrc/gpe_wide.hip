@@ -1,6 +1,7 @@
 // gpe_wide.hip -- launchers of the wide kernel set (gpe_wide.h).  gfx950 only.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <stdlib.h>
 
 #include "gpe_wide.h"
 #include "gpe_wide_api.h"
@@ -35,8 +36,12 @@ void wide_init() {
     (void)hipFuncSetAttribute((const void*)w_forward<HH, CC, EE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);   \
     if (W_NOUT2) (void)hipFuncSetAttribute((const void*)w_forward<HH, CC, EE, W_NOUT2 ? 2 : 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 #define ATTR_B(HH, CC, EE)                                                                                                                \
-    (void)hipFuncSetAttribute((const void*)w_bwd_map<HH, CC, EE, HH / 128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);      \
-    (void)hipFuncSetAttribute((const void*)w_bwd_map<HH, CC, EE, HH / 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);       \
+    (void)hipFuncSetAttribute((const void*)w_bwd_map<HH, CC, EE, HH / 128, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);   \
+    (void)hipFuncSetAttribute((const void*)w_bwd_map<HH, CC, EE, HH / 128, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);    \
+    (void)hipFuncSetAttribute((const void*)w_bwd_map<HH, CC, EE, HH / 128, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);   \
+    (void)hipFuncSetAttribute((const void*)w_bwd_map<HH, CC, EE, HH / 128, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);    \
+    if (W_NOUT2) (void)hipFuncSetAttribute((const void*)w_bwd_map<HH, CC, EE, HH / 128, false, W_NOUT2 ? 2 : 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+    if (W_NOUT2) (void)hipFuncSetAttribute((const void*)w_bwd_map<HH, CC, EE, HH / 128, true, W_NOUT2 ? 2 : 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);  \
     (void)hipFuncSetAttribute((const void*)w_bwd_out<HH, CC, EE, 1, HH / 128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);          \
     if (W_NOUT2) (void)hipFuncSetAttribute((const void*)w_bwd_out<HH, CC, EE, W_NOUT2 ? 2 : 1, HH / 128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     W_FOR_SHAPES(ATTR_F) W_FOR_FWD_ONLY(ATTR_F) W_FOR_SHAPES(ATTR_B)
@@ -74,24 +79,29 @@ static void launch_bwd(const WideCall& a) {
     const int L = a.nd.n_lin - 1;
     const int no = a.nd.n_out;
     const size_t lds_o = ((size_t)((no * HH + no + 3) & ~3) + small4(a.nd, HH)) * sizeof(float);
-    const size_t lds_m = ((size_t)5 * HH + small4(a.nd, HH) + (size_t)CC * NT * 256 + (size_t)CC * W_NW * F_TILE) * sizeof(float);
+    const size_t lds_m = ((size_t)7 * HH + 4 + small4(a.nd, HH) + (size_t)CC * NT * 256 + (size_t)CC * W_NW * F_TILE) * sizeof(float);
     float* zcur = a.Z0;
     float* znext = a.Z1;
-    if (no == 1)
-        hipLaunchKernelGGL((w_bwd_out<HH, CC, EE, 1, NS>), dim3(grid), dim3(512), lds_o, a.stream, a.nd, a.theta, a.pts, a.stored, a.Ob,
-                           zcur, a.gslab, a.N, a.ld, a.Ppad, G);
-    else
-        hipLaunchKernelGGL((w_bwd_out<HH, CC, EE, W_NOUT2 ? 2 : 1, NS>), dim3(grid), dim3(512), lds_o, a.stream, a.nd, a.theta, a.pts,
-                           a.stored, a.Ob, zcur, a.gslab, a.N, a.ld, a.Ppad, G);
-    for (int j = L - 1; j >= 1; --j) {
-        if (j > 1)
-            hipLaunchKernelGGL((w_bwd_map<HH, CC, EE, NS, false>), dim3(grid), dim3(512), lds_m, a.stream, a.nd, j, a.theta, a.WpkT, a.pts,
-                               a.stored, zcur, znext, a.gslab, a.N, a.Ppad, G);
+    static const bool fuse_top = !(getenv("GPE_WIDE_TOP") && atoi(getenv("GPE_WIDE_TOP")) == 0);     // 0: separate w_bwd_out launch
+    if (!fuse_top) {
+        if (no == 1)
+            hipLaunchKernelGGL((w_bwd_out<HH, CC, EE, 1, NS>), dim3(grid), dim3(512), lds_o, a.stream, a.nd, a.theta, a.pts, a.stored, a.Ob,
+                               zcur, a.gslab, a.N, a.ld, a.Ppad, G);
         else
-            hipLaunchKernelGGL((w_bwd_map<HH, CC, EE, NS, true>), dim3(grid), dim3(512), lds_m, a.stream, a.nd, j, a.theta, a.WpkT, a.pts,
-                               a.stored, zcur, znext, a.gslab, a.N, a.Ppad, G);
+            hipLaunchKernelGGL((w_bwd_out<HH, CC, EE, W_NOUT2 ? 2 : 1, NS>), dim3(grid), dim3(512), lds_o, a.stream, a.nd, a.theta, a.pts,
+                               a.stored, a.Ob, zcur, a.gslab, a.N, a.ld, a.Ppad, G);
+    }
+#define MAP_ARGS a.nd, j, a.theta, a.WpkT, a.pts, a.stored, zcur, znext, a.gslab, a.N, a.Ppad, G, a.Ob, a.ld
+#define MAP_LAUNCH(FIRST_, TOP_) hipLaunchKernelGGL((w_bwd_map<HH, CC, EE, NS, FIRST_, TOP_>), dim3(grid), dim3(512), lds_m, a.stream, MAP_ARGS)
+    for (int j = L - 1; j >= 1; --j) {
+        const bool top = fuse_top && j == L - 1;
+        if (!top) { if (j > 1) MAP_LAUNCH(false, 0); else MAP_LAUNCH(true, 0); }
+        else if (no == 1) { if (j > 1) MAP_LAUNCH(false, 1); else MAP_LAUNCH(true, 1); }
+        else { if (j > 1) MAP_LAUNCH(false, (W_NOUT2 ? 2 : 1)); else MAP_LAUNCH(true, (W_NOUT2 ? 2 : 1)); }
         std::swap(zcur, znext);
     }
+#undef MAP_LAUNCH
+#undef MAP_ARGS
 }
 
 int wide_backward(const WideCall& a) {
@@ -100,4 +110,28 @@ int wide_backward(const WideCall& a) {
     W_FOR_SHAPES(CASE_B)
 #undef CASE_B
     return -1;
+}
+
+// diagnostic builds (-DGPE_STAMP) only: read and clear the per-phase cycle counters ([0..7] w_forward, [8..15] w_bwd_map)
+extern "C" int gpe_debug_read_wide_stamps(unsigned long long out[16]) {
+#ifdef GPE_STAMP
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(w_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return -2;
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(w_stamps), z, sizeof z) != hipSuccess) return -2;
+    return 0;
+#else
+    for (int i = 0; i < 16; ++i) out[i] = 0;
+    return -1;
+#endif
+}
+extern "C" int gpe_debug_read_wide_trace(unsigned long long out[256]) {
+#ifdef GPE_STAMP
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(w_trace), 256 * sizeof(unsigned long long)) != hipSuccess) return -2;
+    return 0;
+#else
+    for (int i = 0; i < 16; ++i) out[i] = 0;
+    return -1;
+#endif
 }

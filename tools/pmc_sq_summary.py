@@ -19,7 +19,7 @@ for f in files:
         agg[r["Kernel_Name"].split("(")[0].strip()][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {"command": "rocprofv3 --kernel-trace --pmc <8 SQ counters per pass> --output-format csv -- " + cmd, "kernels": {}}
 for k, d in agg.items():
-    if not any(s in k for s in ("f_forward", "f_backward", "g_fwd", "g_bwd", "w_forward", "w_backward")):
+    if not any(s in k for s in ("f_forward", "f_backward", "g_fwd", "g_bwd", "w_forward", "w_bwd")):
         continue
     m = {c: sum(v) / len(v) for c, v in d.items()}
     n = max(len(v) for v in d.values())
