@@ -1,0 +1,49 @@
+"""CPU: the independent fp64 ground-state solvers (checkers of the |mu - mu_ref| half of the BASELINE metric) against known
+answers and against each other.  oracle/gp_ground_truth.json holds the values the accuracy runs are judged against
+(produced by `python oracle/gp_ground_state_nd.py`, two grids per case)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import gp_ground_state as gs1
+from oracle import gp_ground_state_nd as nd
+
+TRUTH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "gp_ground_truth.json")
+
+
+@pytest.mark.parametrize("omega,n,half", [([1.0], [256], [12.0]), ([1.0, 1.0], [64, 64], [9.0, 9.0]),
+                                           ([1.0, 1.4, 2.0], [40, 36, 32], [7.0, 6.0, 5.0])])
+def test_linear_limit_is_half_sum_omega(omega, n, half):
+    r = nd.ground_state(omega, 0.0, n, half)
+    assert abs(r["mu"] - 0.5 * sum(omega)) < 1e-10 and abs(r["energy"] - 0.5 * sum(omega)) < 1e-10
+
+
+def test_1d_spectral_newton_equals_finite_difference_newton():
+    """two unrelated discretisations (Fourier-spectral / bordered MINRES vs 3-point stencil / sparse LU + Richardson)"""
+    a = nd.ground_state([1.0], 100.0, [512], [16.0])["mu"]
+    lam, _ = gs1.ground_state_1d([100.0], c=0.5, vscale=0.5, half=14.0, n=2401)
+    assert abs(a - float(lam[100.0])) < 2e-6
+    assert abs(a - 14.134287) < 2e-6                      # 14.134
+
+
+def test_2d_g500_value_and_grid_independence():
+    a = nd.ground_state([1.0, 1.0], 500.0, [96, 96], [9.0, 9.0])
+    b = nd.ground_state([1.0, 1.0], 500.0, [128, 128], [10.0, 10.0])
+    assert abs(a["mu"] - b["mu"]) < 1e-6 and b["residual"] < 1e-10
+    assert abs(b["mu"] - 12.678319) < 2e-6                # 12.678 ; E = 8.5118
+    assert abs(b["energy"] - 8.511845) < 2e-6
+    assert abs(b["mu"] - b["mu_from_energy"]) < 1e-9      # mu = E_kin + E_pot + 2 E_int (virial-type identity of the solution)
+    tf = nd.thomas_fermi_mu([1.0, 1.0], 500.0)
+    assert 0 < b["mu"] - tf < 0.1 * tf                    # Thomas-Fermi from below, within its known few-percent error
+
+
+def test_committed_ground_truth_is_consistent():
+    t = json.load(open(TRUTH))
+    for name in ("1d_g100", "2d_g500", "3d_aniso_g1000"):
+        assert t[name]["grid_independence"] < 1e-5, name
+        assert all(g["residual"] < 1e-9 for g in t[name]["grids"])
+    assert abs(t["2d_g500"]["mu"] - 12.678319) < 2e-6
+    assert abs(t["3d_aniso_g1000"]["mu"] - 13.089) < 2e-3   # SURVEY 8(c)'s scratch value, good to ~1e-3
+    assert abs(t["1d_g100"]["mu"] - 14.134287) < 2e-6

@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""BASELINE metric, second half, for the d > 1 / large-g configurations: train the engine to the ground state and compare the
+Rayleigh quotient mu and the density |psi|^2 on a test grid with the independent fp64 spectral-Newton solver
+(oracle/gp_ground_state_nd.py -> oracle/gp_ground_truth.json; checker only).
+
+Schedule (the reference's own strategy, refine/harmonic_pinn_simulation.py:286-407, carried to d dimensions): pre-train the
+network on the analytic g = 0 ground state (pretrain_on_analytical_solution :650-701 -> gpe_mse_step), then continue in gamma
+(gpe_set_gamma) with a fresh Adam + ReduceLROnPlateau per stage, warm-starting from the previous stage's weights.
+
+usage: python tools/accuracy_nd.py --case ns_2d [--epochs 4000 --final 60000 --n 256]"""
+import argparse, json, math, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import gpe_pinn
+from gpe_pinn import capi
+
+CASES = {
+    "ns_2d": dict(layers=[2, 64, 64, 64, 64, 1], omega=(1.0, 1.0), g=500.0, half=8.0, truth="2d_g500", workload="ns_2d_4x64"),
+    "cfg2_1d": dict(layers=[1, 64, 64, 64, 64, 1], omega=(1.0,), g=100.0, half=10.0, truth="1d_g100", workload="cfg2_1d_4x64"),
+    "cfg3_2d": dict(layers=[2, 128, 128, 128, 128, 128, 1], omega=(1.0, 1.0), g=500.0, half=8.0, truth="2d_g500", workload="cfg3_2d_5x128"),
+    "cfg5_3d": dict(layers=[3, 256, 256, 256, 256, 256, 256, 1], omega=(1.0, 1.4, 2.0), g=1000.0, half=6.0, truth="3d_aniso_g1000",
+                    workload="cfg5_3d_6x256"),
+}
+ap = argparse.ArgumentParser()
+ap.add_argument("--case", default="ns_2d", choices=sorted(CASES))
+ap.add_argument("--n", type=int, default=0, help="grid points per axis (0: 256 in 2D, 65536 in 1D, 64 in 3D)")
+ap.add_argument("--pretrain", type=int, default=3000)
+ap.add_argument("--epochs", type=int, default=4000, help="epochs per continuation stage")
+ap.add_argument("--final", type=int, default=60000, help="epochs of the last stage")
+ap.add_argument("--stages", type=int, default=16)
+ap.add_argument("--lr", type=float, default=1e-3)
+ap.add_argument("--w-norm", type=float, default=20.0)
+ap.add_argument("--w-bc", type=float, default=10.0)
+ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--out", default="")
+a = ap.parse_args()
+cs = CASES[a.case]
+d = len(cs["omega"])
+n = a.n or {1: 65536, 2: 256, 3: 64}[d]
+half = cs["half"]
+axes = [np.linspace(-half, half, n) for _ in range(d)]
+h = axes[0][1] - axes[0][0]
+X = np.stack([m.ravel() for m in np.meshgrid(*axes, indexing="ij")], axis=1).astype(np.float32)
+dv = float(h ** d)
+# boundary points: the faces of the box (1D: the two ends)
+if d == 1:
+    xb = np.array([[-half], [half]], np.float32)
+else:
+    t = np.linspace(-half, half, 64 if d == 2 else 12, endpoint=False)
+    faces = []
+    for ax in range(d):
+        others = np.meshgrid(*([t] * (d - 1)), indexing="ij")
+        for side in (-half, half):
+            cols = [o.ravel() for o in others]
+            cols.insert(ax, np.full(cols[0].shape, side))
+            faces.append(np.stack(cols, axis=1))
+    xb = np.concatenate(faces).astype(np.float32)
+
+truth = json.load(open(os.path.join(ROOT, "oracle", "gp_ground_truth.json")))[cs["truth"]]
+mu_ref = truth["mu"]
+
+torch.manual_seed(a.seed)
+import bench
+flat = bench.reference_init(cs["layers"], seed=a.seed)
+cfg = gpe_pinn.GPEConfig(layers=cs["layers"], gamma=0.0, p=3, kinetic_coeff=0.5, pot_scale=0.5, omega=tuple(cs["omega"]) + (1.0,) * (3 - d),
+                         dx=dv, w_bc=a.w_bc, w_norm=a.w_norm, lr=a.lr, sched=capi.SCHED_PLATEAU, factor=0.5, patience=200, min_lr=1e-6,
+                         history_capacity=8)
+eng = gpe_pinn.Engine(cfg)
+eng.set_params(flat)
+xd = torch.as_tensor(X, device="cuda")
+eng.bind_points(xd)
+eng.bind_boundary(torch.as_tensor(xb, device="cuda"))
+t0 = time.time()
+# ---- pre-training on the analytic g = 0 ground state (product of Gaussians) ----
+phi0 = np.ones(X.shape[0])
+for k, w in enumerate(cs["omega"]):
+    phi0 = phi0 * (w / math.pi) ** 0.25 * np.exp(-0.5 * w * X[:, k].astype(np.float64) ** 2)
+eng.bind_target(torch.as_tensor(phi0.astype(np.float32), device="cuda"))
+eng.reset_optimizer(a.lr)
+for i in range(a.pretrain):
+    sc = eng.mse_step() if (i % 500 == 0 or i == a.pretrain - 1) else None
+    if sc is None:
+        eng.lib.gpe_mse_begin(eng._h); eng.lib.gpe_mse_update(eng._h)
+    elif i % 500 == 0:
+        print(f"pretrain {i}: mse {sc['loss']:.3e}", flush=True)
+eng.bind_target(None)
+# ---- gamma continuation ----
+gam = [cs["g"] * (k / a.stages) ** 2 for k in range(a.stages + 1)]            # quadratic ramp: small steps where the state changes fastest
+rows = []
+for si, g in enumerate(gam):
+    eng.set_gamma(g)
+    eng.reset_optimizer(a.lr)
+    ne = a.final if si == len(gam) - 1 else a.epochs
+    eng.run(ne)
+    sc = eng.read_scalars()
+    rows.append(dict(gamma=g, epochs=ne, mu=sc["mu"], loss=sc["loss"], pde=sc["pde"], norm=sc["integral"], lr=sc["lr"]))
+    print(f"stage {si}: gamma {g:8.2f} mu {sc['mu']:.6f} loss {sc['loss']:.3e} pde {sc['pde']:.3e} int {sc['integral']:.6f} lr {sc['lr']:.1e} "
+          f"({time.time() - t0:.0f} s)", flush=True)
+wall = time.time() - t0
+mu = rows[-1]["mu"]
+# ---- density on a test grid vs the solver ----
+from oracle import gp_ground_state_nd as nd
+gr = truth["grids"][0]
+sol = nd.ground_state(truth["problem"]["omega"], truth["problem"]["g"], gr["n"], gr["half"])
+nt = {1: 1000, 2: 96, 3: 24}[d]
+tax = [np.linspace(-0.9 * half, 0.9 * half, nt) for _ in range(d)]
+XT = np.stack([m.ravel() for m in np.meshgrid(*tax, indexing="ij")], axis=1)
+ht = tax[0][1] - tax[0][0]
+u, dens = eng.eval_density(torch.as_tensor(XT.astype(np.float32), device="cuda"), float(ht ** d))
+dens = dens.cpu().numpy().astype(np.float64)
+dens = dens / (dens.sum() * ht ** d)                        # both normalised on the test grid
+dref = nd.density_on(sol["grid"], sol["u"], XT)
+dref = dref / (dref.sum() * ht ** d)
+out = dict(case=a.case, workload=cs["workload"], layers=cs["layers"], points=int(X.shape[0]), grid_per_axis=n, stages=rows,
+           total_epochs=int(sum(r["epochs"] for r in rows)) + a.pretrain, wall_seconds=wall,
+           mu=mu, mu_ref=mu_ref, mu_abs_err=abs(mu - mu_ref), mu_ref_source="oracle/gp_ground_truth.json:" + cs["truth"],
+           density_max_abs_err=float(np.abs(dens - dref).max()), density_max=float(dref.max()),
+           density_rel_l2=float(np.sqrt(((dens - dref) ** 2).sum() / (dref ** 2).sum())),
+           schedule=dict(pretrain=a.pretrain, epochs=a.epochs, final=a.final, stages=a.stages, lr=a.lr, w_norm=a.w_norm, w_bc=a.w_bc,
+                         scheduler="ReduceLROnPlateau(0.5, 200, min 1e-6) per stage"))
+path = a.out or os.path.join(ROOT, "gpurun_out", f"accuracy_{cs['workload']}.json")
+os.makedirs(os.path.dirname(path), exist_ok=True)
+json.dump(out, open(path, "w"), indent=1)
+print(f"mu {mu:.6f}  mu_ref {mu_ref:.6f}  |err| {abs(mu - mu_ref):.2e}   density rel L2 {out['density_rel_l2']:.2e}   {wall:.0f} s")
