@@ -31,6 +31,7 @@ struct Phys {
     float box_L, env_L;
     float perturb_scale, bc_nn_scale;
     float w_pde, w_bc, w_norm, w_sym, w_orth, sym_sign, w_riesz;
+    int riesz_kind;
     float dx;
     double n_global;                 // N of the means
     float inv_world;                 // 1/world_size: scales the replicated boundary batch
@@ -158,6 +159,14 @@ GPE_DEV void act_adjoint(float t, const float* zk, const float* zkk, const float
         acc = fmaf(fmaf(q, S, w2 * zkk[0]), aLb, acc);
     }
     zb[0] = acc;
+}
+
+// Riesz energy  E = (ak sum |grad u|^2 + ap sum V u^2 + ai sum |u|^(p+1)) / (normalised ? sum u^2 : 1)   (gpe_hip.h: riesz_kind)
+GPE_DEV void riesz_coefs(const Phys& ph, float& ak, float& ap, float& ai, bool& normalised) {
+    const float gi = ph.gamma / (float)(ph.p + 1);
+    if (ph.riesz_kind == GPE_RIESZ_SUM) { ak = 0.5f; ap = 0.5f; ai = gi; normalised = false; }
+    else if (ph.riesz_kind == GPE_RIESZ_VARIATIONAL) { ak = ph.kin; ap = 1.0f; ai = 2.0f * gi; normalised = true; }
+    else { ak = 0.5f; ap = 1.0f; ai = gi; normalised = true; }
 }
 
 GPE_DEV float ipowf(float u, int p) {

@@ -86,7 +86,11 @@ __global__ __launch_bounds__(1024) void k_update(int P, float* __restrict__ thet
         double sym = ph.w_sym != 0.f ? sums[S_SYM] / ph.n_global : 0.0;
         double orth = 0.0;
         for (int j = 0; j < ph.n_orth; ++j) { double oj = sums[S_ORTH0 + j] * ph.dx; orth += oj * oj; }
-        double riesz = ph.w_riesz != 0.f ? (sums[S_RZ_K] + sums[S_RZ_P] + sums[S_RZ_I]) / den : 0.0;
+        double riesz = 0.0;
+        if (ph.w_riesz != 0.f) {
+            const double fI = ph.riesz_kind == GPE_RIESZ_VARIATIONAL ? pow(I, -0.5 * (double)(ph.p - 1)) : 1.0;
+            riesz = (sums[S_RZ_K] + sums[S_RZ_P] + fI * sums[S_RZ_I]) / (ph.riesz_kind == GPE_RIESZ_SUM ? 1.0 : den);
+        }
         double loss = ph.w_pde * pde + ph.w_bc * bc + ph.w_norm * nrm + ph.w_sym * sym + ph.w_orth * orth + ph.w_riesz * riesz;
         if (mse_mode) {           // pre-training: loss = mean((NN - target)^2); plain Adam (no clip, no scheduler, no early stop)
             loss = (double)grad[P + GT_MSE_SE2] / (ph.n_global * ph.n_out);
@@ -196,7 +200,7 @@ struct Batch {
     float* Ob = nullptr;
     float* u = nullptr;            // [n_out][ld]  (main batch)
     float* Hu = nullptr;
-    float* ux = nullptr;           // [ld] du/dx (Riesz term, 1D)
+    float* ux = nullptr;           // [dim][ld] grad u (Riesz term)
     float* stored = nullptr;       // fused: fragment-native stored activations
     float* Z0 = nullptr;           // wide set: adjoint-jet ping-pong buffers [tile][C][H/16][256]
     float* Z1 = nullptr;
@@ -318,7 +322,7 @@ static int setup_batch(gpe_engine* e, Batch& b, const float* x, int64_t n, int C
     if (with_head) {
         if ((rc = dev_alloc(e, &b, &b.u, (size_t)no * b.ld))) return rc;
         if ((rc = dev_alloc(e, &b, &b.Hu, (size_t)no * b.ld))) return rc;
-        if ((rc = dev_alloc(e, &b, &b.ux, (size_t)b.ld))) return rc;
+        if ((rc = dev_alloc(e, &b, &b.ux, (size_t)e->nd.dim * b.ld))) return rc;
     }
     const int L = e->nd.n_lin - 1;
     if (e->path == GPE_PATH_FUSED) {
@@ -803,7 +807,7 @@ static void fill_phys(gpe_engine* e) {
     p.base_kind = c.base_kind; p.envelope = c.envelope; p.box_L = c.box_L > 0.f ? c.box_L : 1.f; p.env_L = c.env_L > 0.f ? c.env_L : 1.f;
     p.perturb_scale = c.perturb_scale; p.bc_nn_scale = c.bc_nn_scale;
     p.w_pde = c.w_pde; p.w_bc = c.w_bc; p.w_norm = c.w_norm; p.w_sym = c.w_sym; p.w_orth = c.w_orth;
-    p.sym_sign = c.sym_sign; p.dx = c.dx; p.w_riesz = c.w_riesz;
+    p.sym_sign = c.sym_sign; p.dx = c.dx; p.w_riesz = c.w_riesz; p.riesz_kind = c.riesz_kind;
     p.n_global = (double)(c.n_global > 0 ? c.n_global : (e->n_pde > 0 ? e->n_pde : 1));
     p.inv_world = 1.0f / (float)(c.world_size > 0 ? c.world_size : 1);
     int no = 0;
@@ -910,7 +914,8 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
     if (c.base_kind < 0 || c.base_kind > GPE_BASE_PRECOMPUTED) CFAIL("Unknown base kind: %d", c.base_kind);
     if (c.envelope < 0 || c.envelope > GPE_ENV_SIN) CFAIL("Unknown envelope: %d", c.envelope);
     if (c.envelope != GPE_ENV_NONE && (dim != 1 || no != 1)) CFAIL("the boundary factor needs dim=1, out=1");
-    if (c.w_riesz != 0.f && (dim != 1 || no != 1)) CFAIL("the Riesz energy term needs dim=1, out=1");
+    if (c.w_riesz != 0.f && no != 1) CFAIL("the Riesz energy term needs real psi (out=1)");
+    if (c.riesz_kind < 0 || c.riesz_kind > GPE_RIESZ_VARIATIONAL) CFAIL("Unknown Riesz kind: %d", c.riesz_kind);
     for (int i = 1; i < c.n_layers - 1; ++i)
         if (c.layers[i] < 1 || c.layers[i] > 1024) CFAIL("hidden width %d out of range", c.layers[i]);
     NetDesc& nd = e->nd;
@@ -1720,7 +1725,7 @@ int gpe_set_power(gpe_engine* e, int p) {
 int gpe_set_perturb_scale(gpe_engine* e, float s) { if (!e) return GPE_ERR_INVALID; e->cfg.perturb_scale = s; fill_phys(e); return GPE_OK; }
 int gpe_set_loss_weights(gpe_engine* e, const float w[6]) {
     if (!e || !w) return GPE_ERR_INVALID;
-    if (w[5] != 0.f && (e->nd.dim != 1 || e->nd.n_out != 1)) FAIL(e, GPE_ERR_INVALID, "the Riesz energy term needs dim=1, out=1");
+    if (w[5] != 0.f && e->nd.n_out != 1) FAIL(e, GPE_ERR_INVALID, "the Riesz energy term needs real psi (out=1)");
     if ((w[3] != 0.f) != (e->cfg.w_sym != 0.f)) FAIL(e, GPE_ERR_INVALID, "the symmetry term cannot be switched on/off after bind_points");
     e->cfg.w_pde = w[0]; e->cfg.w_bc = w[1]; e->cfg.w_norm = w[2]; e->cfg.w_sym = w[3]; e->cfg.w_orth = w[4]; e->cfg.w_riesz = w[5];
     fill_phys(e);

@@ -105,13 +105,17 @@ __global__ __launch_bounds__(256) void k_head_pde(Phys ph, float base_norm, Pts 
             den += (double)(u * u);
         }
         for (int j = 0; j < ph.n_orth; ++j) so[j] += (double)(orth[j][m] * U[0][0]);
-        if constexpr (D == 1) {
-            if (ph.w_riesz != 0.f) {            // Paper nb c6:L163-174
-                const float u = U[0][0], ux = U[0][1];
-                ux_out[m] = ux;
-                rzk += 0.5 * (double)(ux * ux);
-                rzp += (double)(V * u * u);
-                rzi += (double)(ph.gamma / (float)(ph.p + 1) * ipowf(fabsf(u), ph.p + 1));
+        if constexpr (D >= 1) {
+            if (ph.w_riesz != 0.f) {            // Paper nb c6:L163-174 ; src/gross_pitaevskii_2D.py:112-151
+                float ak, ap, ai; bool nrm;
+                riesz_coefs(ph, ak, ap, ai, nrm);
+                const float u = U[0][0];
+                float g2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < D; ++k) { const float uk = U[0][1 + k]; ux_out[(int64_t)k * ld + m] = uk; g2 = fmaf(uk, uk, g2); }
+                rzk += (double)(ak * g2);
+                rzp += (double)(ap * V * u * u);
+                rzi += (double)(ai * ipowf(fabsf(u), ph.p + 1));
             }
         }
     }
@@ -188,14 +192,20 @@ __global__ __launch_bounds__(256) void k_seed_pde(Phys ph, Pts x, const float* _
                 for (int j = 0; j < D; ++j) Ub[1 + j] = 0.f;
 #pragma unroll
                 for (int j = 0; j < E; ++j) Ub[1 + D + j] = -ph.kin * rb[o];
-                if constexpr (D == 1) {
-                    if (ph.w_riesz != 0.f) {    // d(w_riesz E)/du, /du_x with E = (K + Pv + Ig)/den
-                        const float den = (float)sums[S_DEN];
-                        const float Erz = (float)((sums[S_RZ_K] + sums[S_RZ_P] + sums[S_RZ_I]) / sums[S_DEN]);
+                if constexpr (D >= 1) {
+                    if (ph.w_riesz != 0.f) {    // d(w_riesz E)/du, /du_k with E = (ak K + ap Pv + ai Ig) / (den | 1)
+                        float ak, ap, ai; bool nrm;
+                        riesz_coefs(ph, ak, ap, ai, nrm);
+                        const float dnm = nrm ? (float)sums[S_DEN] : 1.0f;
+                        // VARIATIONAL: the interaction sum carries fI = I^(-(p-1)/2), I = dx sum u^2 (energy of the normalised state)
+                        const float fI = ph.riesz_kind == GPE_RIESZ_VARIATIONAL ? powf((float)sums[S_DEN] * ph.dx, -0.5f * (float)(ph.p - 1)) : 1.0f;
+                        const float cI = ph.riesz_kind == GPE_RIESZ_VARIATIONAL ? 0.5f * (float)(ph.p + 1) : 1.0f;
+                        const float Erz = nrm ? (float)((sums[S_RZ_K] + sums[S_RZ_P] + (double)(cI * fI) * sums[S_RZ_I]) / sums[S_DEN]) : 0.0f;
                         const float uu = u[0];
                         const float sg = uu < 0.f ? -1.f : 1.f;
-                        Ub[0] += ph.w_riesz * ((2.f * V * uu + ph.gamma * sg * ipowf(fabsf(uu), ph.p)) - 2.f * Erz * uu) / den;
-                        Ub[1] += ph.w_riesz * ux_in[m] / den;
+                        Ub[0] += ph.w_riesz * ((2.f * ap * V * uu + ai * fI * (float)(ph.p + 1) * sg * ipowf(fabsf(uu), ph.p)) - 2.f * Erz * uu) / dnm;
+#pragma unroll
+                        for (int k = 0; k < D; ++k) Ub[1 + k] += ph.w_riesz * 2.f * ak * ux_in[(int64_t)k * ld + m] / dnm;
                     }
                 }
                 if (ph.complex_psi && ph.omega_rot != 0.f && D >= 2) {

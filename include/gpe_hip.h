@@ -57,6 +57,7 @@ enum { GPE_BASE_HERMITE = 0, GPE_BASE_BOX = 1, GPE_BASE_PRECOMPUTED = 2 };
 /* hard boundary factor multiplying the network output in model.forward: none, or sin(pi x / env_L)
  * (refine/box_pinn_simulation.py:119-130) */
 enum { GPE_ENV_NONE = 0, GPE_ENV_SIN = 1 };
+enum { GPE_RIESZ_PAPER = 0, GPE_RIESZ_SUM = 1, GPE_RIESZ_VARIATIONAL = 2 };
 
 typedef struct gpe_engine gpe_engine; /* opaque */
 
@@ -104,10 +105,18 @@ typedef struct gpe_config {
     int32_t envelope;             /* GPE_ENV_* */
     float box_L;                  /* L of the box base */
     float env_L;                  /* L of the sin(pi x / L) factor */
-    /* row f4: Riesz energy term  w_riesz * E,  E = [1/2 sum u_x^2 + sum V u^2 + gamma/(p+1) sum |u|^(p+1)] / sum u^2
-     * (Notebooks/Paper/Gross_Pitaevskii_1D_Harmonic.ipynb c6:L133-183; 1D, real psi) */
+    /* row f4: Riesz energy term  w_riesz * E  (real psi, any dimension), riesz_kind =
+     *   GPE_RIESZ_PAPER       E = [1/2 sum |grad u|^2 + sum V u^2 + gamma/(p+1) sum |u|^(p+1)] / sum u^2
+     *                         (Notebooks/Paper/Gross_Pitaevskii_1D_Harmonic.ipynb c6:L133-183)
+     *   GPE_RIESZ_SUM         E = 1/2 sum |grad u|^2 + 1/2 sum V u^2 + gamma/(p+1) sum |u|^(p+1)   (unnormalised point sums:
+     *                         src/gross_pitaevskii_2D.py:112-151, p = 3: 1/2 (K + P + eta/2 sum u^4))
+     *   GPE_RIESZ_VARIATIONAL E = energy of the NORMALISED state u/sqrt(I), I = dx sum u^2:
+     *                         [c sum |grad u|^2 + sum V u^2] / sum u^2 + 2 gamma/(p+1) sum |u|^(p+1) / (sum u^2 * I^((p-1)/2)).
+     *                         Scale-invariant; its stationary points are exactly the solutions of
+     *                         -c lap v + V v + gamma |v|^(p-1) v = mu v, int v^2 = 1, and its minimiser is the ground state -- the
+     *                         term that keeps training off the excited states without biasing the other loss terms */
     float w_riesz;
-    int32_t reserved_cfg;
+    int32_t riesz_kind;
 } gpe_config;
 
 /* Per-step scalars (refine/...:364-381 keeps loss every 10 and lambda every 100 epochs). */

@@ -43,6 +43,7 @@ POT_HARMONIC, POT_GAUSSIAN, POT_PERIODIC, POT_PRECOMPUTED, POT_NONE = 0, 1, 2, 3
 SCHED_CONST, SCHED_COSINE_LOSS, SCHED_PLATEAU = 0, 1, 2
 BASE_HERMITE, BASE_BOX, BASE_PRECOMPUTED = 0, 1, 2
 ENV_NONE, ENV_SIN = 0, 1
+RIESZ_PAPER, RIESZ_SUM, RIESZ_VARIATIONAL = 0, 1, 2
 
 
 @dataclass
@@ -70,7 +71,8 @@ class Problem:
     w_norm: float = 20.0
     w_sym: float = 0.0
     w_orth: float = 0.0
-    w_riesz: float = 0.0                       # Riesz energy term (Paper nb c6:L133-183; 1D real psi)
+    w_riesz: float = 0.0                       # Riesz energy term (real psi); see riesz_coefs()
+    riesz_kind: int = RIESZ_PAPER              # PAPER: Paper nb c6:L133-183 ; SUM: src/gross_pitaevskii_2D.py:112-151 ; VARIATIONAL
     sym_sign: float = 1.0                      # +1 even mode, -1 odd mode
     base_kind: int = BASE_HERMITE              # refine/box_pinn_simulation.py:99-117 (BOX); caller arrays (PRECOMPUTED)
     envelope: int = ENV_NONE                   # ENV_SIN: forward = NN * sin(pi x / env_L)  (refine/box_pinn_simulation.py:119-130)
@@ -244,6 +246,16 @@ def potential(pb: Problem, x: np.ndarray, V_pre: Optional[np.ndarray] = None) ->
     raise ValueError(f"Unknown potential type: {pb.potential}")
 
 
+def riesz_coefs(pb: "Problem"):
+    """E = (ak sum |grad u|^2 + ap sum V u^2 + ai sum |u|^(p+1)) / (normalised ? sum u^2 : 1)  -> (ak, ap, ai, normalised)"""
+    gi = pb.gamma / (pb.p + 1)
+    if pb.riesz_kind == RIESZ_SUM:             # src/gross_pitaevskii_2D.py:143-149 (p = 3: 1/2 (K + P + 1/2 eta sum u^4))
+        return 0.5, 0.5, gi, False
+    if pb.riesz_kind == RIESZ_VARIATIONAL:     # energy of the normalised state: the interaction sum also carries I^(-(p-1)/2), I = dx sum u^2
+        return pb.kinetic_coeff, 1.0, 2.0 * gi, True
+    return 0.5, 1.0, gi, True                  # Paper nb c6:L163-177
+
+
 def _ipow(u, p: int):
     r = np.ones_like(u)
     for _ in range(p):
@@ -321,11 +333,12 @@ def loss_and_grad(pb: Problem, flat: np.ndarray, x: np.ndarray, x_bc: Optional[n
     n_orth = 0 if orth is None else orth.shape[0]
     for j in range(n_orth):
         sums[f'orth{j}'] = float((orth[j].astype(dt)[:, None] * u).sum(dtype=acc))
-    if pb.w_riesz != 0.0:                                        # Paper nb c6:L163-174 (dx cancels in the quotient)
-        assert d == 1 and pb.n_out == 1
-        sums['rz_k'] = float((0.5 * U[1] * U[1]).sum(dtype=acc))
-        sums['rz_p'] = float((V[:, None] * u * u).sum(dtype=acc))
-        sums['rz_i'] = float((dt.type(pb.gamma / (pb.p + 1)) * _ipow(np.abs(u), pb.p + 1)).sum(dtype=acc))
+    if pb.w_riesz != 0.0:                                        # Paper nb c6:L163-174 (dx cancels in the quotient) ; 2D: src/...2D.py:112-151
+        assert pb.n_out == 1
+        ak, ap, ai, _ = riesz_coefs(pb)
+        sums['rz_k'] = float((dt.type(ak) * (U[1:1 + d] ** 2).sum(axis=0)).sum(dtype=acc))
+        sums['rz_p'] = float((dt.type(ap) * V[:, None] * u * u).sum(dtype=acc))
+        sums['rz_i'] = float((dt.type(ai) * _ipow(np.abs(u), pb.p + 1)).sum(dtype=acc))
     # symmetry term: two value-only passes (notebook c6:L143-147)
     sym = None
     if pb.w_sym != 0.0:
@@ -361,7 +374,14 @@ def loss_and_grad(pb: Problem, flat: np.ndarray, x: np.ndarray, x_bc: Optional[n
     for j in range(n_orth):
         L_orth += (tot[f'orth{j}'] * pb.dx) ** 2
     L_sym = (tot['sym'] / N) if sym is not None else 0.0
-    E_rz = (tot['rz_k'] + tot['rz_p'] + tot['rz_i']) / tot['den'] if pb.w_riesz != 0.0 else 0.0
+    fI = 1.0
+    if pb.w_riesz != 0.0:
+        rz_norm = riesz_coefs(pb)[3]
+        if pb.riesz_kind == RIESZ_VARIATIONAL:
+            fI = (tot['den'] * pb.dx) ** (-0.5 * (pb.p - 1))
+        E_rz = (tot['rz_k'] + tot['rz_p'] + fI * tot['rz_i']) / (tot['den'] if rz_norm else 1.0)
+    else:
+        E_rz = 0.0
     res.update(L_norm=L_norm, L_bc=L_bc, L_orth=L_orth, L_sym=L_sym, L_riesz=E_rz)
     if not want_grad:
         return res
@@ -394,10 +414,15 @@ def loss_and_grad(pb: Problem, flat: np.ndarray, x: np.ndarray, x_bc: Optional[n
     for k in range(d):
         Ub[1 + d + k] = -c * rb
     if pb.w_riesz != 0.0:
-        den = dt.type(tot['den'])
+        ak, ap, ai, rz_norm = riesz_coefs(pb)
+        dnm = dt.type(tot['den']) if rz_norm else dt.type(1.0)
+        cI = 0.5 * (pb.p + 1) if pb.riesz_kind == RIESZ_VARIATIONAL else 1.0
+        Eq = dt.type((tot['rz_k'] + tot['rz_p'] + cI * fI * tot['rz_i']) / tot['den']) if rz_norm else dt.type(0.0)
         wz = dt.type(pb.w_riesz)
-        Ub[0] = Ub[0] + wz * ((2 * V[:, None] * u + g * np.sign(u + (u == 0)) * _ipow(np.abs(u), pb.p)) - 2 * dt.type(E_rz) * u) / den
-        Ub[1] = Ub[1] + wz * U[1] / den
+        Ub[0] = Ub[0] + wz * ((2 * dt.type(ap) * V[:, None] * u
+                               + dt.type(ai * fI * (pb.p + 1)) * np.sign(u + (u == 0)) * _ipow(np.abs(u), pb.p)) - 2 * Eq * u) / dnm
+        for k in range(d):
+            Ub[1 + k] = Ub[1 + k] + wz * dt.type(2 * ak) * U[1 + k] / dnm
     if pb.complex_psi and pb.omega_rot != 0.0:
         Om = dt.type(pb.omega_rot)
         xx, yy = x[:, 0], x[:, 1]

@@ -145,13 +145,29 @@ def epoch_losses(pb: go.Problem, net: nn.Sequential, X: torch.Tensor, x_bc=None,
     norm = (integral - 1.0) ** 2
     total = pb.w_pde * pde + pb.w_norm * norm
     pieces = dict(pde=pde, norm=norm, lam=lam, u=u, r=r, Hu=Hu, nn=u_pred)
-    if getattr(pb, 'w_riesz', 0.0) != 0.0:                   # Notebooks/Paper/Gross_Pitaevskii_1D_Harmonic.ipynb c6:L157-177
-        dxr = X[1] - X[0]
-        norm_factor = torch.sum(u ** 2) * dxr
-        kinetic_term = 0.5 * torch.sum(grads1[0] ** 2) * dxr / norm_factor
-        potential_term = torch.sum(V * u ** 2) * dxr / norm_factor
-        interaction_term = 0.5 * (2.0 * pb.gamma / (pb.p + 1)) * torch.sum(torch.abs(u) ** (pb.p + 1)) * dxr / norm_factor
-        riesz = kinetic_term + potential_term + interaction_term
+    if getattr(pb, 'w_riesz', 0.0) != 0.0:
+        kind = getattr(pb, 'riesz_kind', go.RIESZ_PAPER)
+        if kind == go.RIESZ_PAPER and d == 1:                # Notebooks/Paper/Gross_Pitaevskii_1D_Harmonic.ipynb c6:L157-177, literally
+            dxr = X[1] - X[0]
+            norm_factor = torch.sum(u ** 2) * dxr
+            kinetic_term = 0.5 * torch.sum(grads1[0] ** 2) * dxr / norm_factor
+            potential_term = torch.sum(V * u ** 2) * dxr / norm_factor
+            interaction_term = 0.5 * (2.0 * pb.gamma / (pb.p + 1)) * torch.sum(torch.abs(u) ** (pb.p + 1)) * dxr / norm_factor
+            riesz = kinetic_term + potential_term + interaction_term
+        elif kind == go.RIESZ_SUM and pb.p == 3:             # src/gross_pitaevskii_2D.py:143-149, literally
+            laplacian_term = torch.sum(grads1[0] ** 2)
+            potential_term = torch.sum(V * u ** 2)
+            interaction_term = 0.5 * pb.gamma * torch.sum(u ** 4)
+            riesz = 0.5 * (laplacian_term + potential_term + interaction_term)
+        else:
+            ak, ap, ai, nrm = go.riesz_coefs(pb)
+            S = torch.sum(u ** 2)
+            inter = ai * torch.sum(torch.abs(u) ** (pb.p + 1))
+            if kind == go.RIESZ_VARIATIONAL:                 # energy of the normalised state u / sqrt(dx sum u^2)
+                inter = inter * (pb.dx * S) ** (-0.5 * (pb.p - 1))
+            riesz = ak * torch.sum(grads1[0] ** 2) + ap * torch.sum(V * u ** 2) + inter
+            if nrm:
+                riesz = riesz / S
         total = total + pb.w_riesz * riesz
         pieces['riesz'] = riesz
     if orth is not None and pb.w_orth != 0.0:                # orthogonality penalty (north star; no reference code):

@@ -52,9 +52,11 @@ def fixture(g2d, tag, layers, g, seed, K):
         V = model.compute_potential(xi)
         rows.append([float(u), float(resid), float(lam), float(u_x), float(u_y), float(u_xx), float(u_yy), float(V),
                      float(pde_loss)])
+    xa = torch.tensor(x, requires_grad=True)                        # riesz_loss on all K points in one call (lines 115-146)
+    riesz_all = float(model.riesz_loss(model.forward(xa), xa))
     r = np.array(rows, dtype=np.float64)
     fx = dict(layers=np.array(layers), g=float(g), seed=seed, x=x, flat0=flat0, u=r[:, 0], residual=r[:, 1], lam=r[:, 2],
-              u_x=r[:, 3], u_y=r[:, 4], u_xx=r[:, 5], u_yy=r[:, 6], V=r[:, 7], pde_loss=r[:, 8])
+              u_x=r[:, 3], u_y=r[:, 4], u_xx=r[:, 5], u_yy=r[:, 6], V=r[:, 7], pde_loss=r[:, 8], riesz_all=riesz_all)
     np.savez_compressed(os.path.join(OUT, f"fx_2d_ref_points_{tag}.npz"), **fx)
     print("wrote 2d", tag, "max|u|", np.abs(r[:, 0]).max(), "max|lap|", np.abs(r[:, 5] + r[:, 6]).max())
 

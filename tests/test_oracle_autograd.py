@@ -24,6 +24,12 @@ CASES = {
     "3d_complex": (dict(layers=[3, 12, 12, 2], complex_psi=True, gamma=5.0, dx=0.02), 20),
     "1d_orth2": (dict(layers=[1, 16, 16, 1], gamma=3.0, base_mode=2, w_orth=7.0, dx=0.1), 41),
     "2d_orth1": (dict(layers=[2, 16, 16, 16, 1], gamma=20.0, w_orth=3.0, dx=0.03), 37),
+    "2d_riesz_sum": (dict(layers=[2, 16, 16, 16, 1], gamma=100.0, kinetic_coeff=1.0, pot_scale=1.0, w_riesz=0.3, riesz_kind=go.RIESZ_SUM,
+                          dx=0.02), 45),
+    "2d_riesz_variational": (dict(layers=[2, 16, 16, 16, 1], gamma=500.0, w_riesz=2.0, riesz_kind=go.RIESZ_VARIATIONAL, dx=0.02), 45),
+    "3d_riesz_variational_p2": (dict(layers=[3, 12, 12, 1], gamma=30.0, p=2, abs_power=True, omega=(1.0, 1.4, 2.0), w_riesz=1.5,
+                                     riesz_kind=go.RIESZ_VARIATIONAL, dx=0.02), 30),
+    "2d_riesz_paper": (dict(layers=[2, 12, 12, 1], gamma=10.0, w_riesz=1.0, riesz_kind=go.RIESZ_PAPER, dx=0.02), 30),
     "1d_gauss": (dict(layers=[1, 12, 12, 1], potential=go.POT_GAUSSIAN, pot_a=0.3, gamma=1.0, dx=0.1), 25),
     "1d_periodic": (dict(layers=[1, 12, 12, 1], potential=go.POT_PERIODIC, gamma=1.0, dx=0.1), 25),
 }
@@ -56,7 +62,7 @@ def test_oracle_matches_autograd_fp64(name, detach):
                                     orth=None if orth is None else torch.tensor(orth, dtype=torch.float64))
     total.backward()
     tgrad = tr.get_flat_grad(net)
-    assert abs(float(total) - osc["loss"]) <= 1e-12 * abs(osc["loss"])
+    assert abs(float(total.detach()) - osc["loss"]) <= 1e-12 * abs(osc["loss"])
     assert abs(float(pieces["lam"]) - osc["mu"]) <= 1e-12 * abs(osc["mu"])
     assert abs(float(pieces["pde"]) - osc["pde"]) <= 1e-11 * abs(osc["pde"])
     if "orth" in pieces:

@@ -214,6 +214,11 @@ def test_2d_jets_and_Hu_against_reference_points(name):
     h = go.head_pde(pb, x, jets, V_pre=fx["V"])
     Hu_ref = fx["residual"] + fx["lam"] * fx["u"]
     assert H.rel_err(h["Hu"][:, 0], Hu_ref) < 2e-5
+    # Riesz energy of the same class on all points at once (lines 115-146): 1/2 (sum |grad u|^2 + sum V u^2 + g/2 sum u^4)
+    pbr = go.Problem(layers=layers, kinetic_coeff=1.0, potential=go.POT_PRECOMPUTED, gamma=g, p=3, w_riesz=1.0, riesz_kind=go.RIESZ_SUM,
+                     w_bc=0.0)
+    sc, _, _ = go.full_loss_and_grad(pbr, flat, x, V_pre=fx["V"])
+    assert abs(sc["riesz"] - float(fx["riesz_all"])) < 2e-6 * abs(float(fx["riesz_all"]))
     u = jets[0][:, 0]
     lam_o = (jets[1][:, 0] ** 2 + jets[2][:, 0] ** 2 + fx["V"] * u ** 2 + g * u ** 4) / u ** 2
     big = np.abs(fx["u"]) > 1e-2            # the quotient is ill-conditioned where u ~ 0

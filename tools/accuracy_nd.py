@@ -32,6 +32,7 @@ ap.add_argument("--stages", type=int, default=16)
 ap.add_argument("--lr", type=float, default=1e-3)
 ap.add_argument("--w-norm", type=float, default=20.0)
 ap.add_argument("--w-bc", type=float, default=10.0)
+ap.add_argument("--w-riesz", type=float, default=1.0, help="weight of the variational (normalised-state) energy term; 0: residual loss only")
 ap.add_argument("--seed", type=int, default=0)
 ap.add_argument("--out", default="")
 a = ap.parse_args()
@@ -64,8 +65,8 @@ torch.manual_seed(a.seed)
 import bench
 flat = bench.reference_init(cs["layers"], seed=a.seed)
 cfg = gpe_pinn.GPEConfig(layers=cs["layers"], gamma=0.0, p=3, kinetic_coeff=0.5, pot_scale=0.5, omega=tuple(cs["omega"]) + (1.0,) * (3 - d),
-                         dx=dv, w_bc=a.w_bc, w_norm=a.w_norm, lr=a.lr, sched=capi.SCHED_PLATEAU, factor=0.5, patience=200, min_lr=1e-6,
-                         history_capacity=8)
+                         dx=dv, w_bc=a.w_bc, w_norm=a.w_norm, lr=a.lr, sched=capi.SCHED_CONST, history_capacity=8,
+                         w_riesz=a.w_riesz, riesz_kind=capi.RIESZ_VARIATIONAL)
 eng = gpe_pinn.Engine(cfg)
 eng.set_params(flat)
 xd = torch.as_tensor(X, device="cuda")
@@ -91,11 +92,17 @@ rows = []
 for si, g in enumerate(gam):
     eng.set_gamma(g)
     eng.reset_optimizer(a.lr)
-    ne = a.final if si == len(gam) - 1 else a.epochs
-    eng.run(ne)
+    last = si == len(gam) - 1
+    ne = a.final if last else a.epochs
+    if not last:
+        eng.run(ne)
+    else:                                   # last stage: step the learning rate down (Adam state kept)
+        for frac, lr in ((0.4, a.lr), (0.25, a.lr * 0.3), (0.2, a.lr * 0.1), (0.15, a.lr * 0.03)):
+            eng.set_lr(lr)
+            eng.run(int(ne * frac))
     sc = eng.read_scalars()
-    rows.append(dict(gamma=g, epochs=ne, mu=sc["mu"], loss=sc["loss"], pde=sc["pde"], norm=sc["integral"], lr=sc["lr"]))
-    print(f"stage {si}: gamma {g:8.2f} mu {sc['mu']:.6f} loss {sc['loss']:.3e} pde {sc['pde']:.3e} int {sc['integral']:.6f} lr {sc['lr']:.1e} "
+    rows.append(dict(gamma=g, epochs=ne, mu=sc["mu"], loss=sc["loss"], pde=sc["pde"], norm=sc["integral"], lr=sc["lr"], riesz=sc["riesz"]))
+    print(f"stage {si}: gamma {g:8.2f} mu {sc['mu']:.6f} E {sc['riesz']:.6f} loss {sc['loss']:.3e} pde {sc['pde']:.3e} int {sc['integral']:.6f} lr {sc['lr']:.1e} "
           f"({time.time() - t0:.0f} s)", flush=True)
 wall = time.time() - t0
 mu = rows[-1]["mu"]
@@ -104,21 +111,23 @@ from oracle import gp_ground_state_nd as nd
 gr = truth["grids"][0]
 sol = nd.ground_state(truth["problem"]["omega"], truth["problem"]["g"], gr["n"], gr["half"])
 nt = {1: 1000, 2: 96, 3: 24}[d]
-tax = [np.linspace(-0.9 * half, 0.9 * half, nt) for _ in range(d)]
+tax = [np.linspace(-min(0.9 * half, 0.95 * gr["half"][k]), min(0.9 * half, 0.95 * gr["half"][k]), nt) for k in range(d)]
 XT = np.stack([m.ravel() for m in np.meshgrid(*tax, indexing="ij")], axis=1)
-ht = tax[0][1] - tax[0][0]
-u, dens = eng.eval_density(torch.as_tensor(XT.astype(np.float32), device="cuda"), float(ht ** d))
+ht = float(np.prod([t[1] - t[0] for t in tax]))
+u, dens = eng.eval_density(torch.as_tensor(XT.astype(np.float32), device="cuda"), ht)
 dens = dens.cpu().numpy().astype(np.float64)
-dens = dens / (dens.sum() * ht ** d)                        # both normalised on the test grid
+dens = dens / (dens.sum() * ht)                             # both normalised on the test grid
 dref = nd.density_on(sol["grid"], sol["u"], XT)
-dref = dref / (dref.sum() * ht ** d)
+dref = dref / (dref.sum() * ht)
 out = dict(case=a.case, workload=cs["workload"], layers=cs["layers"], points=int(X.shape[0]), grid_per_axis=n, stages=rows,
            total_epochs=int(sum(r["epochs"] for r in rows)) + a.pretrain, wall_seconds=wall,
            mu=mu, mu_ref=mu_ref, mu_abs_err=abs(mu - mu_ref), mu_ref_source="oracle/gp_ground_truth.json:" + cs["truth"],
            density_max_abs_err=float(np.abs(dens - dref).max()), density_max=float(dref.max()),
            density_rel_l2=float(np.sqrt(((dens - dref) ** 2).sum() / (dref ** 2).sum())),
            schedule=dict(pretrain=a.pretrain, epochs=a.epochs, final=a.final, stages=a.stages, lr=a.lr, w_norm=a.w_norm, w_bc=a.w_bc,
-                         scheduler="ReduceLROnPlateau(0.5, 200, min 1e-6) per stage"))
+                         w_riesz=a.w_riesz,
+                         scheduler="constant lr per stage, fresh Adam per stage; last stage lr x (1, 0.3, 0.1, 0.03)"),
+           energy=rows[-1]["riesz"], energy_ref=truth["energy"])
 path = a.out or os.path.join(ROOT, "gpurun_out", f"accuracy_{cs['workload']}.json")
 os.makedirs(os.path.dirname(path), exist_ok=True)
 json.dump(out, open(path, "w"), indent=1)
