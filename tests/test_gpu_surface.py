@@ -219,3 +219,20 @@ def test_relobralo_balanced_steps_run_and_descend():
         assert all(np.isfinite(v) for v in w.values())
     assert sc["pde"] + sc["riesz"] < first["pde"] + first["riesz"]
     eng.close()
+
+
+# ---- second half of the BASELINE metric for the headline configurations: mu within 1e-3 of the independent fp64 ground truth ----
+@pytest.mark.parametrize("case,extra", [("ns_2d", []), ("cfg2_1d", [])])
+def test_ground_state_mu_within_1e_3(case, extra, tmp_path):
+    """tools/accuracy_nd.py: pre-training on the g = 0 Gaussian, gamma continuation to BASELINE's g with the variational energy
+    term keeping the run on the ground state; mu (Rayleigh quotient of the engine) against oracle/gp_ground_truth.json
+    (spectral Newton, grid-independent to 1e-11) -- 2D g = 500: 12.678319, 1D g = 100: 14.134287 -- and |psi|^2 on a test grid."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "acc.json")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "accuracy_nd.py"), "--case", case, "--out", out] + extra,
+                       capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    d = json.load(open(out))
+    assert d["mu_abs_err"] <= 1e-3, d["mu_abs_err"]
+    assert d["density_rel_l2"] <= 5e-3 and abs(d["energy"] - d["energy_ref"]) <= 1e-3

@@ -31,6 +31,7 @@ ap.add_argument("--final", type=int, default=60000, help="epochs of the last sta
 ap.add_argument("--stages", type=int, default=16)
 ap.add_argument("--lr", type=float, default=1e-3)
 ap.add_argument("--w-norm", type=float, default=20.0)
+ap.add_argument("--w-norm-final", type=float, default=100.0, help="normalisation weight of the last stage (mu scales with the norm: g |u|^2)")
 ap.add_argument("--w-bc", type=float, default=10.0)
 ap.add_argument("--w-riesz", type=float, default=1.0, help="weight of the variational (normalised-state) energy term; 0: residual loss only")
 ap.add_argument("--seed", type=int, default=0)
@@ -96,8 +97,9 @@ for si, g in enumerate(gam):
     ne = a.final if last else a.epochs
     if not last:
         eng.run(ne)
-    else:                                   # last stage: step the learning rate down (Adam state kept)
-        for frac, lr in ((0.4, a.lr), (0.25, a.lr * 0.3), (0.2, a.lr * 0.1), (0.15, a.lr * 0.03)):
+    else:                                   # last stage: tighter normalisation, learning rate stepped down (Adam state kept)
+        eng.set_loss_weights(1.0, a.w_bc, a.w_norm_final, 0.0, 0.0, a.w_riesz)
+        for frac, lr in ((0.35, a.lr), (0.2, a.lr * 0.3), (0.2, a.lr * 0.1), (0.15, a.lr * 0.03), (0.1, a.lr * 0.01)):
             eng.set_lr(lr)
             eng.run(int(ne * frac))
     sc = eng.read_scalars()
@@ -125,8 +127,8 @@ out = dict(case=a.case, workload=cs["workload"], layers=cs["layers"], points=int
            density_max_abs_err=float(np.abs(dens - dref).max()), density_max=float(dref.max()),
            density_rel_l2=float(np.sqrt(((dens - dref) ** 2).sum() / (dref ** 2).sum())),
            schedule=dict(pretrain=a.pretrain, epochs=a.epochs, final=a.final, stages=a.stages, lr=a.lr, w_norm=a.w_norm, w_bc=a.w_bc,
-                         w_riesz=a.w_riesz,
-                         scheduler="constant lr per stage, fresh Adam per stage; last stage lr x (1, 0.3, 0.1, 0.03)"),
+                         w_riesz=a.w_riesz, w_norm_final=a.w_norm_final,
+                         scheduler="constant lr per stage, fresh Adam per stage; last stage lr x (1, 0.3, 0.1, 0.03, 0.01)"),
            energy=rows[-1]["riesz"], energy_ref=truth["energy"])
 path = a.out or os.path.join(ROOT, "gpurun_out", f"accuracy_{cs['workload']}.json")
 os.makedirs(os.path.dirname(path), exist_ok=True)
