@@ -219,7 +219,7 @@ GPE_DEV float potential_at(const Phys& ph, const float* xv, const float* Vpre, i
         case GPE_POT_PRECOMPUTED: return Vpre[m];
         case GPE_POT_HARMONIC: {
             float V = 0.f;
-            for (int k = 0; k < ph.dim; ++k) { float t = ph.omega[k] * xv[k]; V = fmaf(t, t, V); }
+            for (int k = 0; k < ph.dim; ++k) { float t = ph.omega[k] * (xv[k] - (k == 0 ? ph.pot_a : 0.f)); V = fmaf(t, t, V); }
             return ph.pot_scale * V;
         }
         case GPE_POT_GAUSSIAN: { float t = xv[0] - ph.pot_a; return expf(-t * t); }

@@ -229,6 +229,8 @@ class _PINNBase:
         f = self._flavor
         if potential_type == "harmonic":
             omega = kwargs.get("omega", 1.0)
+            if "beta" in kwargs or "center" in kwargs:       # refine/vary_potential_parameter_harmonic.py:231-240
+                return kwargs.get("beta", 1.0) * 0.5 * omega ** 2 * (x - kwargs.get("center", 0.0)) ** 2
             return f.pot_scale * (omega * x) ** 2 if f is _NOTEBOOK else x ** 2
         if potential_type == "gaussian":
             return torch.exp(-(x - kwargs.get("a", 0.0)) ** 2)

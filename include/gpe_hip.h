@@ -71,9 +71,11 @@ typedef struct gpe_config {
     int32_t complex_psi;          /* 1: layers[last]==2, psi = out0 + i*out1 */
     float kinetic_coeff;          /* c in -c*laplacian: 1 (refine/...:181) or 0.5 (nb c6:L113) */
     int32_t potential;            /* GPE_POT_* */
-    float pot_scale;              /* harmonic: V = pot_scale * sum_k (omega[k]*x_k)^2 */
+    float pot_scale;              /* harmonic: V = pot_scale * sum_k (omega[k]*(x_k - c_k))^2, c = (pot_a, 0, 0): the beta-scaled shifted trap
+                                   * V = beta/2 omega^2 (x - center)^2 of refine/vary_potential_parameter_harmonic.py:231-240 is
+                                   * pot_scale = beta/2, omega[0] = omega, pot_a = center */
     float omega[GPE_MAX_DIM];
-    float pot_a, pot_v0, pot_k;   /* gaussian centre; periodic depth, wave number */
+    float pot_a, pot_v0, pot_k;   /* gaussian centre (and harmonic trap centre along x); periodic depth, wave number */
     float omega_rot;              /* rotation frequency Omega: -Omega*L_z psi (complex psi, dim>=2) */
     float gamma;                  /* interaction strength (refine/...:184) */
     int32_t p;                    /* nonlinearity power: gamma*u^p */

@@ -55,7 +55,7 @@ class Problem:
     potential: int = POT_HARMONIC
     pot_scale: float = 0.5                     # harmonic: V = pot_scale * sum (omega_k x_k)^2
     omega: Sequence[float] = (1.0, 1.0, 1.0)
-    pot_a: float = 0.0                         # gaussian centre
+    pot_a: float = 0.0                         # gaussian centre; harmonic: centre of the trap along x
     pot_v0: float = 1.0                        # periodic depth
     pot_k: float = 2 * math.pi / 5.0           # periodic wave number
     omega_rot: float = 0.0                     # rotation frequency (complex psi, d>=2)
@@ -235,7 +235,8 @@ def potential(pb: Problem, x: np.ndarray, V_pre: Optional[np.ndarray] = None) ->
         V = np.zeros(x.shape[0], dtype=dt)
         for k in range(x.shape[1]):
             w = dt.type(pb.omega[k])
-            V = V + (w * x[:, k]) ** 2
+            c = dt.type(pb.pot_a if k == 0 else 0.0)   # trap centre along x (refine/vary_potential_parameter_harmonic.py:231-240)
+            V = V + (w * (x[:, k] - c)) ** 2
         return dt.type(pb.pot_scale) * V
     if pb.potential == POT_GAUSSIAN:            # notebook c6:L71-72
         return np.exp(-(x[:, 0] - dt.type(pb.pot_a)) ** 2)

@@ -80,7 +80,7 @@ def _potential(pb: go.Problem, x: torch.Tensor, V_pre):
     if pb.potential == go.POT_HARMONIC:
         V = 0
         for k in range(x.shape[1]):
-            V = V + (pb.omega[k] * x[:, k:k + 1]) ** 2
+            V = V + (pb.omega[k] * (x[:, k:k + 1] - (pb.pot_a if k == 0 else 0.0))) ** 2
         return pb.pot_scale * V
     if pb.potential == go.POT_GAUSSIAN:
         return torch.exp(-(x[:, 0:1] - pb.pot_a) ** 2)

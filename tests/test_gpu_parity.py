@@ -54,6 +54,9 @@ CASES = {
     "1d_64x4_m3_p4_odd": (dict(layers=[1, 64, 64, 64, 64, 1], activation=1, gamma=2.0, p=4, base_mode=3, perturb_scale=0.1,
                                w_sym=5.0, sym_sign=-1.0, dx=12 / 1000), 1001, True),
     "1d_abs_power_p2": (dict(layers=[1, 32, 32, 1], gamma=3.0, p=2, abs_power=True, base_mode=1, dx=0.03), 333, True),
+    # beta-scaled SHIFTED trap V = beta/2 omega^2 (x - center)^2 (refine/vary_potential_parameter_harmonic.py:231-240): beta = 0.7, omega = 3
+    "1d_shifted_beta_trap": (dict(layers=[1, 32, 32, 32, 1], activation=1, kinetic_coeff=1.0, pot_scale=0.35, omega=(3.0, 1.0, 1.0),
+                                  pot_a=0.7, gamma=4.0, dx=0.03), 300, True),
     "1d_gaussian_pot": (dict(layers=[1, 32, 32, 32, 1], potential=go.POT_GAUSSIAN, pot_a=0.5, gamma=1.0, dx=0.03), 200, True),
     "1d_periodic_pot": (dict(layers=[1, 32, 32, 32, 1], potential=go.POT_PERIODIC, gamma=1.0, dx=0.03), 200, True),
     "2d_64x4_g500": (dict(layers=[2, 64, 64, 64, 64, 1], gamma=500.0, dx=36 / 777), 777, True),
@@ -751,3 +754,35 @@ def test_native_rccl_step_equals_plain_step(path):
     with pytest.raises(gpe_pinn.GPEError):
         a.step_dp()                                   # no communicator: loud
     a.close(); b.close()
+
+
+# ---- BASELINE configs[2..4] at their PER-GPU size: the two kernel sets are independent implementations; sums and gradients must
+#      agree at full size (size-independent cross-check; the oracle pins the same shapes at small N in test_step_matches_oracle) --------
+FULL_SIZE = {
+    "cfg3_2d_5x128_131072": (dict(layers=[2, 128, 128, 128, 128, 128, 1], gamma=500.0), (512, 256), 8.0),
+    "cfg4_2d_6x128_rot_262144": (dict(layers=[2, 128, 128, 128, 128, 128, 128, 2], gamma=500.0, complex_psi=True, omega_rot=0.8),
+                                 (512, 512), 8.0),
+    "cfg5_3d_6x256_524288": (dict(layers=[3, 256, 256, 256, 256, 256, 256, 1], gamma=1000.0, omega=(1.0, 1.4, 2.0)), (64, 128, 64), 6.0),
+}
+
+
+@pytest.mark.parametrize("name", sorted(FULL_SIZE))
+def test_fused_and_generic_agree_at_per_gpu_size(name):
+    kw, grid, half = FULL_SIZE[name]
+    axes = [np.linspace(-half, half, n, dtype=np.float32) for n in grid]
+    x = np.stack([m.ravel() for m in np.meshgrid(*axes, indexing="ij")], axis=1)
+    dx = float(np.prod([2 * half / (n - 1) for n in grid]))
+    rng = np.random.default_rng(2)
+    flat = (rng.normal(0, 1, go.param_count(kw["layers"])) * _scale(kw)).astype(np.float32)
+    pb = go.Problem(**kw, dx=dx)
+    outs = {}
+    for path in ("generic", "fused"):
+        eng = make_engine(pb, flat, x, None, path=PATHS[path])
+        sc = eng.step()
+        outs[path] = (sc, eng.get_grad())
+        eng.close()
+        torch.cuda.empty_cache()
+    (a, ga), (b, gb) = outs["generic"], outs["fused"]
+    assert abs(a["mu"] - b["mu"]) < 1e-5 * abs(a["mu"])
+    assert abs(a["loss"] - b["loss"]) < 1e-4 * abs(a["loss"])
+    assert H.rel_err(gb, ga) < 3e-4
