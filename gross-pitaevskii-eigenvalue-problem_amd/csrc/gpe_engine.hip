@@ -220,7 +220,8 @@ struct gpe_engine {
     hipStream_t stream = nullptr;
     int path = GPE_PATH_GENERIC;
     int H = 0;                     // uniform hidden width (fused)
-    bool wide = false;             // fused path served by the wide kernel set (gpe_wide.h): H = 256, or H = 128 in 3D
+    bool wide = false;             // fused path: reverse pass by the wide kernel set (gpe_wide.h): H = 256 or 128
+    bool wide_fwd = false;         // ... and the forward pass too (H = 256, H = 128 in 3D; H = 128 in 1D/2D keeps f_forward_coop: measured)
     int P = 0, Ppad = 0;
     float base_norm = 1.f;
     float *theta = nullptr, *am = nullptr, *av = nullptr, *grad = nullptr;   // grad: P + GT_COUNT
@@ -596,7 +597,7 @@ static int mlp_forward(gpe_engine* e, Batch& b, bool store) {
         if (rc) return rc;
         unsigned grid = fused_grid(e, b.n, 4, 2);
         if (mark) prof_mark(e, 0, true);
-        if (e->wide) {
+        if (e->wide_fwd) {
             const int wr = wide_forward(wide_call(e, b), store ? 1 : 0);
             if (wr < 0) FAIL(e, GPE_ERR_INVALID, "wide kernel set: channels (%d,%d) / n_out %d not compiled", b.C, b.E, e->nd.n_out);
             if (wr) FAIL(e, GPE_ERR_HIP, "w_forward launch: %s", hipGetErrorString((hipError_t)wr));
@@ -867,9 +868,10 @@ int gpe_active_kernels(gpe_engine* e, char* buf, size_t n) {
     char f[160], r[160];
     const int maps = e->nd.n_lin - 2;
     if (e->path == GPE_PATH_FUSED && e->wide) {
-        snprintf(f, sizeof f, "w_forward<%d,%d,%d,%d>", e->H, b.C, b.E, e->nd.n_out);
-        snprintf(r, sizeof r, "w_bwd_out<%d,%d,%d,%d,%d> + %d x w_bwd_map<%d,%d,%d,%d>", e->H, b.C, b.E, e->nd.n_out, e->H / 128, maps,
-                 e->H, b.C, b.E, e->H / 128);
+        if (e->wide_fwd) snprintf(f, sizeof f, "w_forward<%d,%d,%d,%d>", e->H, b.C, b.E, e->nd.n_out);
+        else if (fwd_coop(e, b)) snprintf(f, sizeof f, "f_forward_coop<%d,%d,%d,%d,%d>", e->H, b.C, b.E, e->nd.n_out, maps > 5 ? 5 : maps);
+        else snprintf(f, sizeof f, "f_forward<%d,%d,%d,%d,l2>", e->H, b.C, b.E, e->nd.n_out);
+        snprintf(r, sizeof r, "%d x w_bwd_map<%d,%d,%d,%d> (output layer fused into the top map)", maps, e->H, b.C, b.E, e->H / 128);
     } else if (e->path == GPE_PATH_FUSED) {
         const bool fc = fwd_coop(e, b) && (e->H <= 64 || b.C <= 4);
         if (fc) snprintf(f, sizeof f, "f_forward_coop<%d,%d,%d,%d,%d>", e->H, b.C, b.E, e->nd.n_out, maps > 5 ? 5 : maps);
@@ -938,8 +940,13 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
     size_t lds_need = ((size_t)e->Ppad + (size_t)(8 + c.n_layers + 2) * c.layers[1] + 8 + 4 * (dim + 2) * F_TILE) * sizeof(float);
     bool fused_ok = uniform && (H == 32 || H == 64) && Lh >= 2 && lds_need <= 160 * 1024;
     if (uniform && H == 128 && Lh >= 2 && dim <= 2) fused_ok = true;          // cooperative kernels, weights streamed from L2
-    const char* envw = getenv("GPE_WIDE");                                     // 1: H = 128 takes the wide set in every dimension
-    if (uniform && Lh >= 2 && (H == 256 || (H == 128 && (dim == 3 || (envw && atoi(envw) != 0))))) { fused_ok = true; e->wide = true; }
+    // wide kernel set: H = 256 and 3D H = 128 entirely; 1D/2D H = 128: its per-map reverse kernels (no register spills, -5..7 % against
+    // f_backward_coop<128>) behind the cooperative forward kernel (7 % faster than w_forward there) -- same stored-activation format.
+    // GPE_WIDE=1: forward too; GPE_WIDE=0: cooperative kernels only (1D/2D)
+    const char* envw = getenv("GPE_WIDE");
+    const int wmode = envw ? atoi(envw) : -1;
+    if (uniform && Lh >= 2 && (H == 256 || (H == 128 && dim == 3))) { fused_ok = true; e->wide = true; e->wide_fwd = true; }
+    else if (uniform && Lh >= 2 && H == 128 && wmode != 0) { fused_ok = true; e->wide = true; e->wide_fwd = wmode == 1; }
     if (c.path == GPE_PATH_FUSED && !fused_ok)
         CFAIL("fused path needs >=2 hidden layers of one width: 32 or 64 (P*4 <= 160KB LDS), 128 or 256");
     e->path = (c.path == GPE_PATH_GENERIC || !fused_ok) ? GPE_PATH_GENERIC : GPE_PATH_FUSED;

@@ -555,13 +555,13 @@ def test_side_stream_and_graph_replay_change_nothing(kw, N):
     (dict(layers=[1, 32, 32, 32, 1], gamma=5.0, base_mode=0, dx=0.01), 1000,
      [{"GPE_COOP": "1"}, {"GPE_COOP": "0", "GPE_STAGE_MIN_TILES": "0"}, {"GPE_COOP": "0", "GPE_STAGE_MIN_TILES": "1000000000"}]),
     (dict(layers=[2, 128, 128, 128, 1], gamma=50.0, dx=0.01), 777,
-     [{"GPE_COOP128": "1", "GPE_COOP_FWD128": "1"}, {"GPE_COOP128": "0", "GPE_COOP_FWD128": "0"},
-      {"GPE_COOP128": "1", "GPE_COOP_FWD128": "0"}]),
+     [{"GPE_WIDE": "0", "GPE_COOP128": "1", "GPE_COOP_FWD128": "1"}, {"GPE_WIDE": "0", "GPE_COOP128": "0", "GPE_COOP_FWD128": "0"},
+      {"GPE_WIDE": "0", "GPE_COOP128": "1", "GPE_COOP_FWD128": "0"}, {}, {"GPE_WIDE": "1"}]),
 ])
 def test_kernel_variants_agree(kw, N, envs):
     """The fused path has several kernels for the same two primitives -- cooperative (a workgroup per tile), per-wave-tile with
     LDS-staged weights + register-resident gradients, per-wave-tile unstaged with LDS-atomic gradients, global-atomic slabs for
-    H = 128 -- selected by shape and batch size.  One step from the same state must agree to fp32 round-off whichever runs."""
+    H = 128, the wide set's per-map reverse kernels (default for H = 128) -- selected by shape and batch size.  One step from the same state must agree to fp32 round-off whichever runs."""
     scale = _scale(kw)
     ref = None
     seen = set()
