@@ -25,6 +25,7 @@ PATH_AUTO, PATH_GENERIC, PATH_FUSED = 0, 1, 2
 BASE_HERMITE, BASE_BOX, BASE_PRECOMPUTED = 0, 1, 2
 ENV_NONE, ENV_SIN = 0, 1
 RIESZ_PAPER, RIESZ_SUM, RIESZ_VARIATIONAL = 0, 1, 2
+NET_MLP, NET_RESIDUAL = 0, 1
 
 
 class gpe_config(C.Structure):
@@ -43,7 +44,7 @@ class gpe_config(C.Structure):
         ("path", C.c_int32), ("world_size", C.c_int32), ("history_capacity", C.c_int32),
         ("stop_tol", C.c_float), ("stop_patience", C.c_int32),
         ("base_kind", C.c_int32), ("envelope", C.c_int32), ("box_L", C.c_float), ("env_L", C.c_float),
-        ("w_riesz", C.c_float), ("riesz_kind", C.c_int32),
+        ("w_riesz", C.c_float), ("riesz_kind", C.c_int32), ("net_kind", C.c_int32), ("reserved_cfg", C.c_int32),
     ]
 
 

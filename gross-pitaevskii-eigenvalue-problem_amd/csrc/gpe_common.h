@@ -11,7 +11,9 @@ struct NetDesc {
     int n_lin;                       // number of nn.Linear
     int dim;                         // width[0]
     int n_out;                       // width[n_lin]
-    float shift;                     // 0 (tanh) or 1 (tanh+1)
+    float shift;                     // 0 (tanh) or 1 (tanh+1)  (plain MLP: every hidden layer; fused / wide kernel sets)
+    float shiftv[GPE_MAX_LAYERS];    // per hidden layer (generic set; residual blocks use plain tanh behind a shifted first layer)
+    int skip[GPE_MAX_LAYERS];        // map j: hidden layer whose activation jets are added to its output before the activation, or -1
     int width[GPE_MAX_LAYERS];
     int offW[GPE_MAX_LAYERS];        // offsets into the flat (torch-order) parameter vector
     int offB[GPE_MAX_LAYERS];

@@ -207,6 +207,7 @@ struct Batch {
     std::vector<float*> S;         // generic: per hidden layer [C][H][ld]
     float* A0 = nullptr;           // generic adjoint ping/pong [C][maxW][ld]
     float* A1 = nullptr;
+    float* A2 = nullptr;           // third adjoint buffer (residual networks: a block's output adjoint waits for the skip join)
     float* xown = nullptr;         // owned copy of points (symmetry batch)
     std::vector<void*> allocs;
 };
@@ -345,6 +346,7 @@ static int setup_batch(gpe_engine* e, Batch& b, const float* x, int64_t n, int C
         }
         if ((rc = dev_alloc(e, &b, &b.A0, (size_t)C * maxW * b.ld))) return rc;
         if ((rc = dev_alloc(e, &b, &b.A1, (size_t)C * maxW * b.ld))) return rc;
+        if (e->cfg.net_kind == GPE_NET_RESIDUAL && (rc = dev_alloc(e, &b, &b.A2, (size_t)C * maxW * b.ld))) return rc;
     }
     return GPE_OK;
 }
@@ -627,22 +629,23 @@ static int mlp_forward(gpe_engine* e, Batch& b, bool store) {
         for (int lin = 0; lin < nd.n_lin; ++lin) {
             const float* Sprev = lin > 0 ? b.S[lin - 1] : nullptr;
             float* Out = (lin == nd.n_lin - 1) ? b.O : b.S[lin];
-            if (lin > 0 && nd.width[lin] % 64 == 0 && nd.width[lin + 1] % 256 == 0 && e->gen_mfma && e->gen_mfma2) {
+            const float* Sskip = nd.skip[lin] >= 0 ? b.S[nd.skip[lin]] : nullptr;     // residual block: the VALU kernel adds the block input
+            if (!Sskip && lin > 0 && nd.width[lin] % 64 == 0 && nd.width[lin + 1] % 256 == 0 && e->gen_mfma && e->gen_mfma2) {
                 dim3 grid(cdiv(b.n, 16), nd.width[lin + 1] / 256);      // a block = one point tile x 256 outputs, jets shared through LDS
                 DISPATCH_FWD(b, hipLaunchKernelGGL((g_fwd_layer_mfma2<CC, EE>), grid, dim3(256), 0, e->stream, nd, lin, e->theta,
                                                     Sprev, Out, b.n, b.ld));
-            } else if (lin > 0 && nd.width[lin] % 64 == 0 && nd.width[lin + 1] % 64 == 0 && e->gen_mfma) {   // wide map: matrix cores
+            } else if (!Sskip && lin > 0 && nd.width[lin] % 64 == 0 && nd.width[lin + 1] % 64 == 0 && e->gen_mfma) {   // wide map: matrix cores
                 dim3 grid(cdiv(cdiv(b.n, 16), 4), nd.width[lin + 1] / 64);
                 DISPATCH_FWD(b, hipLaunchKernelGGL((g_fwd_layer_mfma<CC, EE>), grid, dim3(256), 0, e->stream, nd, lin, e->theta,
                                                     Sprev, Out, b.n, b.ld));
             } else if (nd.width[lin + 1] >= 64) {      // wide layer: 16 output features per thread
                 dim3 grid(cdiv(b.n, 256), cdiv(nd.width[lin + 1], G_FBW));
                 DISPATCH_FWD(b, hipLaunchKernelGGL((g_fwd_layer<CC, EE, G_FBW>), grid, dim3(256), 0, e->stream, nd, lin, e->theta,
-                                                    b.pts, Sprev, Out, b.n, b.ld));
+                                                    b.pts, Sprev, Out, b.n, b.ld, Sskip));
             } else {
                 dim3 grid(cdiv(b.n, 256), cdiv(nd.width[lin + 1], G_FB));
                 DISPATCH_FWD(b, hipLaunchKernelGGL((g_fwd_layer<CC, EE, G_FB>), grid, dim3(256), 0, e->stream, nd, lin, e->theta,
-                                                    b.pts, Sprev, Out, b.n, b.ld));
+                                                    b.pts, Sprev, Out, b.n, b.ld, Sskip));
             }
         }
     }
@@ -716,9 +719,12 @@ static int mlp_backward(gpe_engine* e, Batch& b, bool close = false, bool assign
         const NetDesc& nd = e->nd;
         float* Zb = b.Ob;
         float* nxt = b.A0;
+        const float* skip_adj = nullptr;          // zbar of a residual block's second map: joins the adjoint of the block input
+        int skip_to = -1;
         for (int lin = nd.n_lin - 1; lin >= 0; --lin) {
             const int K = nd.width[lin], Ho = nd.width[lin + 1];
             const float* Sprev = lin > 0 ? b.S[lin - 1] : nullptr;
+            if (nd.skip[lin] >= 0) { skip_adj = Zb; skip_to = nd.skip[lin]; }
             if (lin > 0 && Ho % 128 == 0 && K % 128 == 0 && e->gen_mfma && e->gen_mfma2) {
                 // wide hidden->hidden map, 128 x 128 block tiles with LDS-shared operand panels
                 const int64_t want = (int64_t)e->num_cu * 4 / ((Ho / 128) * (K / 128)) + 1;       // ~4 blocks per CU
@@ -759,7 +765,8 @@ static int mlp_backward(gpe_engine* e, Batch& b, bool close = false, bool assign
             }
             if (lin > 0) {
                 bool act_done = false;
-                if (K % 256 == 0 && Ho % 64 == 0 && e->gen_mfma && e->gen_mfma2) {
+                const bool join = skip_adj && skip_to == lin - 1;      // the skipped-from layer: its adjoint gets the saved zbar first
+                if (!join && K % 256 == 0 && Ho % 64 == 0 && e->gen_mfma && e->gen_mfma2) {
                     dim3 gd(cdiv(b.n, 16), K / 256);             // activation adjoint of layer lin-1 fused into the epilogue
                     DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_data_mfma2<CC, EE>), gd, dim3(256), 0, e->stream, nd, lin, e->theta, Zb,
                                                         nxt, Sprev, b.n, b.ld));
@@ -777,12 +784,19 @@ static int mlp_backward(gpe_engine* e, Batch& b, bool close = false, bool assign
                     DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_data<CC, G_FB>), gd, dim3(256), 0, e->stream, nd, lin, e->theta, Zb,
                                                         nxt, b.n, b.ld));
                 }
+                if (join) {
+                    const int64_t cnt = (int64_t)b.C * K * b.ld;
+                    hipLaunchKernelGGL(g_add, dim3(cdiv(cnt, 256)), dim3(256), 0, e->stream, nxt, skip_adj, cnt);
+                    skip_adj = nullptr; skip_to = -1;
+                }
                 if (!act_done) {
                     dim3 ga(cdiv(b.n, 256), K);
                     DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_act<CC, EE>), ga, dim3(256), 0, e->stream, K, Sprev, nxt, b.n, b.ld));
                 }
                 Zb = nxt;
-                nxt = (nxt == b.A0) ? b.A1 : b.A0;
+                // next free adjoint buffer: not the one just written, not one still waiting for its skip join
+                float* cand[3] = {b.A0, b.A1, b.A2};
+                for (float* c2 : cand) if (c2 && c2 != Zb && c2 != skip_adj) { nxt = c2; break; }
             }
         }
         if (close) {
@@ -922,9 +936,24 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
         if (c.layers[i] < 1 || c.layers[i] > 1024) CFAIL("hidden width %d out of range", c.layers[i]);
     NetDesc& nd = e->nd;
     memset(&nd, 0, sizeof nd);
-    nd.n_lin = c.n_layers - 1; nd.dim = dim; nd.n_out = no; nd.shift = c.activation == GPE_ACT_TANH_PLUS1 ? 1.f : 0.f;
+    nd.dim = dim; nd.n_out = no; nd.shift = c.activation == GPE_ACT_TANH_PLUS1 ? 1.f : 0.f;
+    if (c.net_kind != GPE_NET_MLP && c.net_kind != GPE_NET_RESIDUAL) CFAIL("Unknown network kind: %d", c.net_kind);
+    for (int j = 0; j < GPE_MAX_LAYERS; ++j) { nd.skip[j] = -1; nd.shiftv[j] = nd.shift; }
+    if (c.net_kind == GPE_NET_RESIDUAL) {      // refine/box_to_gaussian_pinn_simulation.py:100-130
+        const int nb = c.n_layers - 3;
+        if (nb < 1 || 2 * nb + 3 > GPE_MAX_LAYERS) CFAIL("residual network: 1..%d blocks", (GPE_MAX_LAYERS - 3) / 2);
+        for (int i = 2; i < c.n_layers - 1; ++i) if (c.layers[i] != c.layers[1]) CFAIL("residual network: one hidden width");
+        nd.n_lin = 2 * nb + 2;
+        nd.width[0] = dim;
+        for (int i = 1; i <= 2 * nb + 1; ++i) nd.width[i] = c.layers[1];
+        nd.width[nd.n_lin] = no;
+        for (int bq = 0; bq < nb; ++bq) nd.skip[2 * bq + 2] = 2 * bq;     // lin2 of block bq adds hidden layer 2 bq (the block input)
+        for (int h = 1; h < nd.n_lin - 1; ++h) nd.shiftv[h] = 0.f;        // plain tanh inside the blocks; the first layer keeps `activation`
+    } else {
+        nd.n_lin = c.n_layers - 1;
+        for (int i = 0; i < c.n_layers; ++i) nd.width[i] = c.layers[i];
+    }
     int off = 0;
-    for (int i = 0; i < c.n_layers; ++i) nd.width[i] = c.layers[i];
     for (int j = 0; j < nd.n_lin; ++j) {
         nd.offW[j] = off; off += nd.width[j] * nd.width[j + 1];
         nd.offB[j] = off; off += nd.width[j + 1];
@@ -938,6 +967,7 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
     const int H = c.layers[1];
     const int Lh = c.n_layers - 2;
     size_t lds_need = ((size_t)e->Ppad + (size_t)(8 + c.n_layers + 2) * c.layers[1] + 8 + 4 * (dim + 2) * F_TILE) * sizeof(float);
+    if (c.net_kind == GPE_NET_RESIDUAL) uniform = false;                        // residual blocks: generic set only
     bool fused_ok = uniform && (H == 32 || H == 64) && Lh >= 2 && lds_need <= 160 * 1024;
     if (uniform && H == 128 && Lh >= 2 && dim <= 2) fused_ok = true;          // cooperative kernels, weights streamed from L2
     // wide kernel set: H = 256 and 3D H = 128 entirely; 1D/2D H = 128: its per-map reverse kernels (no register spills, -5..7 % against

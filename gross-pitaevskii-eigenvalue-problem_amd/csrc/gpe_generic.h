@@ -19,7 +19,8 @@
 template <int C, int E, int FB>
 __global__ __launch_bounds__(256) void g_fwd_layer(NetDesc nd, int lin, const float* __restrict__ theta,
                                                    Pts x, const float* __restrict__ Sprev,
-                                                   float* __restrict__ Out, int64_t N, int64_t ld) {
+                                                   float* __restrict__ Out, int64_t N, int64_t ld,
+                                                   const float* __restrict__ Sskip /* stored of hidden layer nd.skip[lin], or NULL */) {
     constexpr int D = C - 1 - E;
     int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (m >= N) return;
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void g_fwd_layer(NetDesc nd, int lin, const fl
             for (int j = 0; j < D; ++j) zk[j] = Sprev[((int64_t)(1 + j) * K + k) * ld + m];
 #pragma unroll
             for (int j = 0; j < E; ++j) zkk[j] = Sprev[((int64_t)(1 + D + j) * K + k) * ld + m];
-            act_from_stored<D, E>(t, zk, zkk, nd.shift, a);
+            act_from_stored<D, E>(t, zk, zkk, nd.shiftv[lin - 1], a);
 #pragma unroll
             for (int f = 0; f < FB; ++f) {
                 int n = min(n0 + f, Ho - 1);
@@ -68,6 +69,21 @@ __global__ __launch_bounds__(256) void g_fwd_layer(NetDesc nd, int lin, const fl
         }
     }
     const bool last = (lin == nd.n_lin - 1);
+    if (Sskip) {      // residual block (refine/box_to_gaussian_pinn_simulation.py:58-62): z += activation jets of the block's input
+        const float sh = nd.shiftv[nd.skip[lin]];
+#pragma unroll
+        for (int f = 0; f < FB; ++f) {
+            const int n = min(n0 + f, Ho - 1);
+            float zk[D > 0 ? D : 1], zkk[E > 0 ? E : 1], a[C];
+#pragma unroll
+            for (int j = 0; j < D; ++j) zk[j] = Sskip[((int64_t)(1 + j) * Ho + n) * ld + m];
+#pragma unroll
+            for (int j = 0; j < E; ++j) zkk[j] = Sskip[((int64_t)(1 + D + j) * Ho + n) * ld + m];
+            act_from_stored<D, E>(Sskip[((int64_t)0 * Ho + n) * ld + m], zk, zkk, sh, a);
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[f][c] += a[c];
+        }
+    }
 #pragma unroll
     for (int f = 0; f < FB; ++f) {
         int n = n0 + f;
@@ -97,6 +113,12 @@ __global__ __launch_bounds__(256) void g_bwd_act(int H, const float* __restrict_
     act_adjoint<D, E>(t, zk, zkk, ab, zb);
 #pragma unroll
     for (int c = 0; c < C; ++c) A[((int64_t)c * H + n) * ld + m] = zb[c];
+}
+
+// A[i] += B[i]: the adjoint arriving over a skip connection joins the adjoint of the skipped-from activations
+__global__ void g_add(float* __restrict__ A, const float* __restrict__ B, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) A[i] += B[i];
 }
 
 // Aprev[c][k][m] = sum_n W[n][k] Zb[c][n][m].   grid (ceil(N/256), ceil(K/G_FB)).
@@ -188,7 +210,7 @@ __global__ __launch_bounds__(256) void g_bwd_weight(NetDesc nd, int lin, Pts x,
                 for (int j = 0; j < D; ++j) zk[j] = Sprev[((int64_t)(1 + j) * K + k) * ld + m];
 #pragma unroll
                 for (int j = 0; j < E; ++j) zkk[j] = Sprev[((int64_t)(1 + D + j) * K + k) * ld + m];
-                act_from_stored<D, E>(t, zk, zkk, nd.shift, a);
+                act_from_stored<D, E>(t, zk, zkk, nd.shiftv[lin - 1], a);
 #pragma unroll
                 for (int r = 0; r < NB; ++r) {
                     float v = 0.f;
@@ -267,7 +289,7 @@ __global__ __launch_bounds__(256, 1) void g_bwd_weight_mfma(NetDesc nd, int lin,
                 for (int j = 0; j < D; ++j) zk[j] = st[1 + j][s2];
 #pragma unroll
                 for (int j = 0; j < E; ++j) zkk[j] = st[1 + D + j][s2];
-                act_from_stored<D, E>(st[0][s2], zk, zkk, nd.shift, av);
+                act_from_stored<D, E>(st[0][s2], zk, zkk, nd.shiftv[lin - 1], av);
 #pragma unroll
                 for (int c = 0; c < C; ++c) a[kt][c][s2] = av[c];
             }
@@ -351,7 +373,7 @@ __global__ __launch_bounds__(256) void g_fwd_layer_mfma(NetDesc nd, int lin, con
             for (int j = 0; j < D; ++j) zk[j] = Sprev[((int64_t)(1 + j) * K + k) * ld + mp];
 #pragma unroll
             for (int j = 0; j < E; ++j) zkk[j] = Sprev[((int64_t)(1 + D + j) * K + k) * ld + mp];
-            act_from_stored<D, E>(t, zk, zkk, nd.shift, a);
+            act_from_stored<D, E>(t, zk, zkk, nd.shiftv[lin - 1], a);
 #pragma unroll
             for (int c = 0; c < C; ++c)
 #pragma unroll
@@ -463,7 +485,7 @@ __global__ __launch_bounds__(256, 1) void g_bwd_weight_mfma2(NetDesc nd, int lin
                 for (int j = 0; j < D; ++j) zk[j] = st[1 + j][s2];
 #pragma unroll
                 for (int j = 0; j < E; ++j) zkk[j] = st[1 + D + j][s2];
-                act_from_stored<D, E>(st[0][s2], zk, zkk, nd.shift, a1);
+                act_from_stored<D, E>(st[0][s2], zk, zkk, nd.shiftv[lin - 1], a1);
 #pragma unroll
                 for (int c = 0; c < C; ++c) av[c][s2] = a1[c];
             }
@@ -555,7 +577,7 @@ __global__ __launch_bounds__(256) void g_fwd_layer_mfma2(NetDesc nd, int lin, co
             for (int j = 0; j < D; ++j) zk[j] = Sprev[((int64_t)(1 + j) * K + k) * ld + mp];
 #pragma unroll
             for (int j = 0; j < E; ++j) zkk[j] = Sprev[((int64_t)(1 + D + j) * K + k) * ld + mp];
-            act_from_stored<D, E>(t, zk, zkk, nd.shift, a);
+            act_from_stored<D, E>(t, zk, zkk, nd.shiftv[lin - 1], a);
 #pragma unroll
             for (int c = 0; c < C; ++c) PB[c][i][kl] = a[c];
         }

@@ -75,6 +75,7 @@ class GPEConfig:
     env_L: float = 1.0
     w_riesz: float = 0.0
     riesz_kind: int = capi.RIESZ_PAPER
+    net_kind: int = capi.NET_MLP
 
     def to_c(self) -> capi.gpe_config:
         c = capi.gpe_config()
@@ -89,7 +90,7 @@ class GPEConfig:
         for i in range(3):
             c.omega[i] = float(om[i])
         for name in ("activation", "potential", "p", "base_mode", "base_deriv", "sched", "patience", "path",
-                     "world_size", "history_capacity", "n_global", "stop_patience", "base_kind", "envelope", "riesz_kind"):
+                     "world_size", "history_capacity", "n_global", "stop_patience", "base_kind", "envelope", "riesz_kind", "net_kind"):
             setattr(c, name, int(getattr(self, name)))
         c.complex_psi = int(bool(self.complex_psi))
         c.abs_power = int(bool(self.abs_power))

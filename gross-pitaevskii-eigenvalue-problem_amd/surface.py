@@ -49,43 +49,59 @@ def _layer_shapes(layers):
     return [(layers[i + 1], layers[i]) for i in range(len(layers) - 1)]
 
 
-def _state_dict_from_flat(flat: np.ndarray, layers) -> "OrderedDict[str, torch.Tensor]":
+def _mlp_spec(layers):
+    """[(state_dict key prefix, out, in)] of nn.Sequential(Linear, act, Linear, ...): keys network.{2k}"""
+    return [(f"network.{2 * k}", fo, fi) for k, (fo, fi) in enumerate(_layer_shapes(layers))]
+
+
+def _residual_spec(layers):
+    """refine/box_to_gaussian_pinn_simulation.py:112-130: network.0 = Linear(d,H), network.1 = ShiftedTanh, network.{2+b} =
+    ResidualBlock b (lin1, lin2), network.{2+nb} = Linear(H,out)"""
+    d, H, out, nb = layers[0], layers[1], layers[-1], len(layers) - 3
+    spec = [("network.0", H, d)]
+    for b in range(nb):
+        spec += [(f"network.{2 + b}.lin1", H, H), (f"network.{2 + b}.lin2", H, H)]
+    return spec + [(f"network.{2 + nb}", out, H)]
+
+
+def _state_dict_from_flat(flat: np.ndarray, layers, spec=None) -> "OrderedDict[str, torch.Tensor]":
     """keys network.{2k}.weight / .bias as nn.Sequential(Linear, act, Linear, ...) gives them."""
     sd, o = OrderedDict(), 0
-    for k, (fo, fi) in enumerate(_layer_shapes(layers)):
-        sd[f"network.{2 * k}.weight"] = torch.from_numpy(flat[o:o + fo * fi].reshape(fo, fi).copy()); o += fo * fi
-        sd[f"network.{2 * k}.bias"] = torch.from_numpy(flat[o:o + fo].copy()); o += fo
+    for key, fo, fi in (spec or _mlp_spec(layers)):
+        sd[f"{key}.weight"] = torch.from_numpy(flat[o:o + fo * fi].reshape(fo, fi).copy()); o += fo * fi
+        sd[f"{key}.bias"] = torch.from_numpy(flat[o:o + fo].copy()); o += fo
     return sd
 
 
-def _flat_from_state_dict(sd, layers) -> np.ndarray:
+def _flat_from_state_dict(sd, layers, spec=None) -> np.ndarray:
     parts = []
-    for k, (fo, fi) in enumerate(_layer_shapes(layers)):
-        W = sd[f"network.{2 * k}.weight"]
-        b = sd[f"network.{2 * k}.bias"]
+    for key, fo, fi in (spec or _mlp_spec(layers)):
+        k = key
+        W = sd[f"{key}.weight"]
+        b = sd[f"{key}.bias"]
         W = W.detach().cpu().numpy() if isinstance(W, torch.Tensor) else np.asarray(W)
         b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
         if W.shape != (fo, fi) or b.shape != (fo,):
-            raise RuntimeError(f"size mismatch for network.{2 * k}: got {W.shape}/{b.shape}, expected {(fo, fi)}/{(fo,)}")
+            raise RuntimeError(f"size mismatch for {k}: got {W.shape}/{b.shape}, expected {(fo, fi)}/{(fo,)}")
         parts += [W.astype(np.float32).ravel(), b.astype(np.float32).ravel()]
     return np.concatenate(parts)
 
 
-def _default_init(layers) -> np.ndarray:
+def _default_init(layers, spec=None) -> np.ndarray:
     """nn.Linear's default init (kaiming_uniform(a=sqrt 5) + uniform bias), drawn from torch's global CPU RNG in the same
     order the reference's constructor draws it (refine/...:90)."""
     parts = []
-    for fo, fi in _layer_shapes(layers):
+    for fo, fi in ([(a, b) for _, a, b in spec] if spec else _layer_shapes(layers)):
         lin = torch.nn.Linear(fi, fo)
         parts += [lin.weight.detach().numpy().ravel(), lin.bias.detach().numpy().ravel()]
     return np.concatenate(parts).astype(np.float32)
 
 
-def _advanced_init(layers, mode, kind) -> np.ndarray:
+def _advanced_init(layers, mode, kind, spec=None) -> np.ndarray:
     """advanced_initialization: refine/...:636-647 (Xavier-normal, gain 1/(1+0.2 mode), bias 0.01 | 0.001 if mode>3);
     nb c18 (Xavier-uniform, gain 1/(1+0.1 mode), bias 0.01).  Uses torch's CPU RNG exactly as model.apply() does."""
     parts = []
-    for fo, fi in _layer_shapes(layers):
+    for fo, fi in ([(a, b) for _, a, b in spec] if spec else _layer_shapes(layers)):
         W = torch.empty(fo, fi)
         if kind == "xavier_normal":
             torch.nn.init.xavier_normal_(W, gain=1.0 / (1.0 + 0.2 * mode))
@@ -112,7 +128,7 @@ class _PINNBase:
     def __init__(self, layers, hbar=1.0, m=1.0, mode=0, gamma=1.0):
         self.layers = list(layers)
         self.hbar, self.m, self.mode, self.gamma = hbar, m, mode, gamma
-        self._flat = _default_init(self.layers)           # nn.Linear default init, as the reference constructor does
+        self._flat = _default_init(self.layers, self._spec())     # nn.Linear default init, as the reference constructor does
         self._engine: Optional[Engine] = None
         self._engine_key = None
         self.perturb_scale = 1.0
@@ -138,12 +154,15 @@ class _PINNBase:
     def parameters(self):
         return [torch.from_numpy(self._flat)]
 
+    def _spec(self):
+        return None                                        # plain MLP: network.{2k}
+
     def state_dict(self):
         self._pull()
-        return _state_dict_from_flat(self._flat, self.layers)
+        return _state_dict_from_flat(self._flat, self.layers, self._spec())
 
     def load_state_dict(self, sd):
-        self._flat = _flat_from_state_dict(sd, self.layers)
+        self._flat = _flat_from_state_dict(sd, self.layers, self._spec())
         if self._engine is not None:
             self._engine.set_params(self._flat)
 
@@ -318,6 +337,42 @@ class _BoxPINN(_RefinePINN):
         return super().pde_loss(inputs, predictions, gamma, p, potential_type, precomputed_potential)
 
 
+class _BoxToGaussianPINN(_RefinePINN):
+    """refine/box_to_gaussian_pinn_simulation.py:66-240: box [0, L] with the Gaussian bump V = exp(-(x - 0.5)^2) inside; sine base
+    sqrt(2/L) sin((n+1) pi x / L) (:132-150); forward = network(x) (no boundary factor, :152-156); the network is
+    Linear + ShiftedTanh, len(layers)-3 ResidualBlocks tanh(lin2(tanh(lin1 x)) + x), Linear (:100-130) when use_residual (default),
+    else the plain ShiftedTanh MLP."""
+
+    def __init__(self, layers, hbar=1.0, m=1.0, mode=0, gamma=1.0, L=1.0, use_residual=True):
+        self.use_residual = bool(use_residual)
+        self.L = L
+        super().__init__(layers, hbar, m, mode, gamma, True)
+
+    def _spec(self):
+        return _residual_spec(self.layers) if self.use_residual else None
+
+    def _extra_config(self):
+        return dict(base_kind=capi.BASE_BOX, box_L=float(self.L), potential=capi.POT_GAUSSIAN, pot_a=0.5,
+                    net_kind=capi.NET_RESIDUAL if self.use_residual else capi.NET_MLP)
+
+    def box_eigenfunction(self, x, n):
+        return math.sqrt(2.0 / self.L) * torch.sin((n + 1) * math.pi * x / self.L)
+
+    def weighted_hermite(self, x, n):            # the base of this flavour
+        return self.box_eigenfunction(x, n)
+
+    def weighted_hermite_np(self, x, n):
+        return (math.sqrt(2.0 / self.L) * np.sin((n + 1) * math.pi * np.asarray(x, np.float64) / self.L)).astype(np.float32)
+
+    def compute_potential(self, x, potential_type="gaussian", **kwargs):
+        if potential_type != "gaussian":
+            raise ValueError(f"Unknown potential type: {potential_type}")
+        return torch.exp(-(x - 0.5) ** 2)
+
+    def pde_loss(self, inputs, predictions, gamma, p, potential_type="gaussian", precomputed_potential=None):
+        return super().pde_loss(inputs, predictions, gamma, p, potential_type, precomputed_potential)
+
+
 class _GravityWellPINN(_RefinePINN):
     """refine/gravity_well_pinn_simulation.py:52-260: V = x on [0, ub]; base Psi_n = Ai(x + alpha_n) normalised on the grid,
     Psi' from scipy's Ai', Psi'' by np.gradient (as the reference does, :141-173).  Like the reference, the base is computed on
@@ -407,7 +462,7 @@ def _history(eng: Engine, first: int, last: int, chunk: int = 8192):
 # refine flavour driver
 # ================================================================================================
 def _refine_advanced_initialization(m, mode):
-    m._flat = _advanced_init(m.layers, mode, "xavier_normal")
+    m._flat = _advanced_init(m.layers, mode, "xavier_normal", m._spec())
     if m._engine is not None:
         m._engine.set_params(m._flat)
 
@@ -568,7 +623,7 @@ def _refine_wavefunction(model, X_test, constant, perturb_const, mode=None):
 # notebook flavour driver
 # ================================================================================================
 def _nb_advanced_initialization(m, mode):
-    m._flat = _advanced_init(m.layers, mode, "xavier_uniform")
+    m._flat = _advanced_init(m.layers, mode, "xavier_uniform", m._spec())
     if m._engine is not None:
         m._engine.set_params(m._flat)
 
@@ -656,6 +711,18 @@ def _gravity_train(gamma_values, modes, p, X_train, lb, ub, layers, epochs, tol,
                          verbose, _cls=_GravityWellPINN, **kw)
 
 
+def _b2g_train(gamma_values, modes, p, X_train, lb, ub, layers, epochs, tol, perturb_const, potential_type="gaussian", lr=1e-5,
+               verbose=True, **kw):
+    """train_gpe_model of refine/box_to_gaussian_pinn_simulation.py:242-449 (the same loop; no pre-training there: :316-320)."""
+    if potential_type != "gaussian":
+        raise ValueError(f"Unknown potential type: {potential_type}")
+    kw.setdefault("pretrain", None)
+    return _refine_train(gamma_values, modes, p, X_train, lb, ub, layers, epochs, tol, perturb_const, "gaussian", lr, verbose,
+                         _cls=_BoxToGaussianPINN, L=float(ub), **kw)
+
+
+box_to_gaussian = types.SimpleNamespace(GrossPitaevskiiPINN=_BoxToGaussianPINN, train_gpe_model=_b2g_train,
+                                        advanced_initialization=_refine_advanced_initialization)
 gravity_well = types.SimpleNamespace(GrossPitaevskiiPINN=_GravityWellPINN, train_gpe_model=_gravity_train,
                                      advanced_initialization=_refine_advanced_initialization,
                                      pretrain_on_analytical_solution=_refine_pretrain)

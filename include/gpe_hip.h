@@ -58,6 +58,7 @@ enum { GPE_BASE_HERMITE = 0, GPE_BASE_BOX = 1, GPE_BASE_PRECOMPUTED = 2 };
  * (refine/box_pinn_simulation.py:119-130) */
 enum { GPE_ENV_NONE = 0, GPE_ENV_SIN = 1 };
 enum { GPE_RIESZ_PAPER = 0, GPE_RIESZ_SUM = 1, GPE_RIESZ_VARIATIONAL = 2 };
+enum { GPE_NET_MLP = 0, GPE_NET_RESIDUAL = 1 };
 
 typedef struct gpe_engine gpe_engine; /* opaque */
 
@@ -119,6 +120,11 @@ typedef struct gpe_config {
      *                         term that keeps training off the excited states without biasing the other loss terms */
     float w_riesz;
     int32_t riesz_kind;
+    /* row f3: network flavour.  GPE_NET_RESIDUAL: layers = [d, H, ..., H, out] describes Linear(d,H) + activation, len(layers)-3
+     * residual blocks  tanh(lin2(tanh(lin1 x)) + x)  and Linear(H,out) (refine/box_to_gaussian_pinn_simulation.py:52-63,100-130);
+     * parameters in state_dict order network.0, network.2.lin1, network.2.lin2, network.3.lin1, ... (generic kernel set) */
+    int32_t net_kind;
+    int32_t reserved_cfg;
 } gpe_config;
 
 /* Per-step scalars (refine/...:364-381 keeps loss every 10 and lambda every 100 epochs). */

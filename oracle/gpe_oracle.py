@@ -44,6 +44,7 @@ SCHED_CONST, SCHED_COSINE_LOSS, SCHED_PLATEAU = 0, 1, 2
 BASE_HERMITE, BASE_BOX, BASE_PRECOMPUTED = 0, 1, 2
 ENV_NONE, ENV_SIN = 0, 1
 RIESZ_PAPER, RIESZ_SUM, RIESZ_VARIATIONAL = 0, 1, 2
+NET_MLP, NET_RESIDUAL = 0, 1
 
 
 @dataclass
@@ -78,6 +79,8 @@ class Problem:
     envelope: int = ENV_NONE                   # ENV_SIN: forward = NN * sin(pi x / env_L)  (refine/box_pinn_simulation.py:119-130)
     box_L: float = 1.0
     env_L: float = 1.0
+    net_kind: int = NET_MLP                    # NET_RESIDUAL: refine/box_to_gaussian_pinn_simulation.py:52-63,100-130 (layers = [d, H, ..., H, out],
+                                               #   len(layers) - 3 residual blocks tanh(lin2(tanh(lin1 x)) + x) behind Linear(d,H) + activation)
     dx: float = 1.0                            # quadrature weight
     n_global: int = 0                          # N used in the means (0 -> len(x))
 
@@ -90,15 +93,34 @@ class Problem:
         return int(self.layers[-1])
 
 
-def param_count(layers: Sequence[int]) -> int:
-    return sum(layers[i] * layers[i + 1] + layers[i + 1] for i in range(len(layers) - 1))
+def expand_layers(layers: Sequence[int], net_kind: int = NET_MLP):
+    """-> (widths of the linear maps' ends, skip[j] = hidden layer whose jets are added to map j's output before its activation or -1,
+    plain_tanh[h] = True when hidden layer h uses tanh without the ShiftedTanh shift)."""
+    layers = [int(v) for v in layers]
+    if net_kind == NET_MLP:
+        n_lin = len(layers) - 1
+        return layers, [-1] * n_lin, [False] * (n_lin - 1)
+    assert len(layers) >= 4 and len(set(layers[1:-1])) == 1, "residual network: layers = [d, H, ..., H, out]"
+    nb, H = len(layers) - 3, layers[1]
+    widths = [layers[0]] + [H] * (2 * nb + 1) + [layers[-1]]
+    skip = [-1] * (2 * nb + 2)
+    for b in range(nb):
+        skip[2 * b + 2] = 2 * b                 # lin2 of block b adds the block input = hidden layer 2b
+    return widths, skip, [False] + [True] * (2 * nb)
 
 
-def unflatten(flat: np.ndarray, layers: Sequence[int]) -> List[Tuple[np.ndarray, np.ndarray]]:
-    """flat is in torch state_dict order: network.0.weight [out,in], network.0.bias, network.2.weight ..."""
+def param_count(layers: Sequence[int], net_kind: int = NET_MLP) -> int:
+    w = expand_layers(layers, net_kind)[0]
+    return sum(w[i] * w[i + 1] + w[i + 1] for i in range(len(w) - 1))
+
+
+def unflatten(flat: np.ndarray, layers: Sequence[int], net_kind: int = NET_MLP) -> List[Tuple[np.ndarray, np.ndarray]]:
+    """flat is in torch state_dict order: network.0.weight [out,in], network.0.bias, network.2.weight ...
+    (residual network: network.0, network.2.lin1, network.2.lin2, network.3.lin1, ..., output Linear)"""
+    w = expand_layers(layers, net_kind)[0]
     out, o = [], 0
-    for i in range(len(layers) - 1):
-        fi, fo = layers[i], layers[i + 1]
+    for i in range(len(w) - 1):
+        fi, fo = w[i], w[i + 1]
         W = flat[o:o + fi * fo].reshape(fo, fi); o += fi * fo
         b = flat[o:o + fo]; o += fo
         out.append((W, b))
@@ -114,8 +136,8 @@ def flatten(params: List[Tuple[np.ndarray, np.ndarray]]) -> np.ndarray:
 # MLP with derivative jets.  Channel layout: 0 = value, 1..d = d/dx_k, d+1..2d = d2/dx_k^2
 # (value_only -> a single channel).
 # ----------------------------------------------------------------------------------------
-def mlp_forward(params, x: np.ndarray, activation: int, value_only: bool = False):
-    """x [N,d] -> out jets [C,N,n_out]; cache for the reverse pass."""
+def mlp_forward(params, x: np.ndarray, activation: int, value_only: bool = False, skip=None, plain_tanh=None):
+    """x [N,d] -> out jets [C,N,n_out]; cache for the reverse pass.  skip / plain_tanh: expand_layers() of a residual network."""
     dt = x.dtype
     N, d = x.shape
     C = 1 if value_only else 1 + 2 * d
@@ -124,8 +146,8 @@ def mlp_forward(params, x: np.ndarray, activation: int, value_only: bool = False
     if not value_only:
         for k in range(d):
             A[1 + k, :, k] = 1
-    shift = dt.type(1.0) if activation == 1 else dt.type(0.0)
     cache = []
+    acts = []
     L = len(params)
     for l, (W, b) in enumerate(params):
         Z = A @ W.T.astype(dt)                  # [C,N,out]   (harmonic_pinn_simulation.py:90 nn.Linear)
@@ -133,6 +155,9 @@ def mlp_forward(params, x: np.ndarray, activation: int, value_only: bool = False
         if l == L - 1:
             cache.append((A, None, None, Z))
             return Z, cache
+        if skip is not None and skip[l] >= 0:   # box_to_gaussian_pinn_simulation.py:58-62: tanh(lin2(...) + identity)
+            Z = Z + acts[skip[l]]
+        shift = dt.type(1.0) if (activation == 1 and not (plain_tanh is not None and plain_tanh[l])) else dt.type(0.0)
         t = np.tanh(Z[0])                       # harmonic_pinn_simulation.py:48-49 / notebook c6:L38
         s = 1 - t * t
         An = np.empty_like(Z)
@@ -143,21 +168,25 @@ def mlp_forward(params, x: np.ndarray, activation: int, value_only: bool = False
                 An[1 + k] = s * zk
                 An[1 + d + k] = s * zkk - 2 * t * s * zk * zk
         cache.append((A, t, s, Z))
+        acts.append(An)
         A = An
 
 
-def mlp_backward(params, cache, out_bar: np.ndarray, value_only: bool = False):
+def mlp_backward(params, cache, out_bar: np.ndarray, value_only: bool = False, skip=None):
     """out_bar [C,N,n_out] = dLoss/d(out jets).  Returns the flat gradient (torch state_dict order)."""
     L = len(params)
     grads = [None] * L
     d = params[0][0].shape[1]
     Zb = out_bar
+    pending = {}                                 # hidden layer index -> adjoint arriving over a skip connection
     for l in range(L - 1, -1, -1):
         W, b = params[l]
         A, t, s, Z = cache[l]
         dt = A.dtype
         if l < L - 1:
             Ab = Zb                              # adjoint of this layer's activation jets
+            if l in pending:
+                Ab = Ab + pending.pop(l)
             Zb = np.empty_like(Ab)
             ts2 = -2 * t * s
             acc = s * Ab[0]
@@ -170,6 +199,8 @@ def mlp_backward(params, cache, out_bar: np.ndarray, value_only: bool = False):
                     Zb[1 + k] = s * akb - 4 * t * s * zk * akkb
                     acc = acc + ts2 * zk * akb + (ts2 * zkk + q * zk * zk) * akkb
             Zb[0] = acc
+            if skip is not None and skip[l] >= 0:
+                pending[skip[l]] = Zb            # z = lin(a) + a_skip: the same adjoint flows into the skipped-from activations
         # weight / bias gradients:  dW = sum_c Zb_c^T A_c ; db = sum_m Zb_0
         gW = np.einsum('cmo,cmi->oi', Zb, A)
         gb = Zb[0].sum(axis=0)
@@ -325,8 +356,9 @@ def loss_and_grad(pb: Problem, flat: np.ndarray, x: np.ndarray, x_bc: Optional[n
     dt = x.dtype
     N_loc, d = x.shape
     N = pb.n_global if pb.n_global > 0 else N_loc
-    params = unflatten(flat.astype(dt), pb.layers)
-    out, cache = mlp_forward(params, x, pb.activation)
+    params = unflatten(flat.astype(dt), pb.layers, pb.net_kind)
+    _, skip, plain = expand_layers(pb.layers, pb.net_kind)
+    out, cache = mlp_forward(params, x, pb.activation, skip=skip, plain_tanh=plain)
     h = head_pde(pb, x, out, V_pre, base_pre)
     u, Hu, V, U = h['u'], h['Hu'], h['V'], h['U']
     acc = np.float64
@@ -343,8 +375,8 @@ def loss_and_grad(pb: Problem, flat: np.ndarray, x: np.ndarray, x_bc: Optional[n
     # symmetry term: two value-only passes (notebook c6:L143-147)
     sym = None
     if pb.w_sym != 0.0:
-        o1, c1 = mlp_forward(params, x, pb.activation, value_only=True)
-        o2, c2 = mlp_forward(params, -x, pb.activation, value_only=True)
+        o1, c1 = mlp_forward(params, x, pb.activation, value_only=True, skip=skip, plain_tanh=plain)
+        o2, c2 = mlp_forward(params, -x, pb.activation, value_only=True, skip=skip, plain_tanh=plain)
         diff = o1[0] - dt.type(pb.sym_sign) * o2[0]
         sums['sym'] = float((diff * diff).sum(dtype=acc))
         sym = (diff, c1, c2)
@@ -363,7 +395,7 @@ def loss_and_grad(pb: Problem, flat: np.ndarray, x: np.ndarray, x_bc: Optional[n
     # boundary term (replicated on every shard; :198-210)
     L_bc = 0.0
     if x_bc is not None and pb.w_bc != 0.0:
-        ob, cb = mlp_forward(params, x_bc.astype(dt), pb.activation, value_only=True)
+        ob, cb = mlp_forward(params, x_bc.astype(dt), pb.activation, value_only=True, skip=skip, plain_tanh=plain)
         fenv_b = envelope(pb, x_bc[:, 0].astype(dt))[0][:, None] if pb.envelope == ENV_SIN else dt.type(1.0)
         fb = dt.type(pb.bc_nn_scale) * fenv_b * ob[0]
         if pb.base_mode >= 0 and pb.base_kind != BASE_PRECOMPUTED:
@@ -437,18 +469,18 @@ def loss_and_grad(pb: Problem, flat: np.ndarray, x: np.ndarray, x_bc: Optional[n
         f, f1, f2 = (a[:, None] for a in envelope(pb, x[:, 0]))
         u0, u1, u2 = out_bar[0], out_bar[1], out_bar[2]
         out_bar = np.stack([f * u0 + f1 * u1 + f2 * u2, f * u1 + 2 * f1 * u2, f * u2])
-    grad = mlp_backward(params, cache, out_bar).astype(acc)
+    grad = mlp_backward(params, cache, out_bar, skip=skip).astype(acc)
     if x_bc is not None and pb.w_bc != 0.0:
         ebar = (dt.type(pb.w_bc * 2.0 / eb.size) * eb) * dt.type(pb.bc_nn_scale) * fenv_b
-        gbc = mlp_backward(params, cb, ebar[None], value_only=True).astype(acc)
+        gbc = mlp_backward(params, cb, ebar[None], value_only=True, skip=skip).astype(acc)
         res['grad_bc'] = gbc                                     # identical on every shard
     else:
         res['grad_bc'] = np.zeros_like(grad)
     if sym is not None:
         diff, c1, c2 = sym
         sb = dt.type(pb.w_sym * 2.0 / N) * diff
-        grad = grad + mlp_backward(params, c1, sb[None], value_only=True)
-        grad = grad + mlp_backward(params, c2, (-dt.type(pb.sym_sign) * sb)[None], value_only=True)
+        grad = grad + mlp_backward(params, c1, sb[None], value_only=True, skip=skip)
+        grad = grad + mlp_backward(params, c2, (-dt.type(pb.sym_sign) * sb)[None], value_only=True, skip=skip)
     res['grad_local'] = grad                                     # to be summed over shards
     res['psi'] = u
     res['residual'] = r
@@ -579,8 +611,9 @@ def train_steps(pb: Problem, st: OptState, flat: np.ndarray, x, n_steps: int, x_
 def eval_density(pb: Problem, flat: np.ndarray, x_test: np.ndarray, dx: float, abs_mode0: bool = False):
     """plot_wavefunction (:463-474) / notebook c12:L30-42: forward on the test grid, + base, renormalise."""
     dt = x_test.dtype
-    params = unflatten(flat.astype(dt), pb.layers)
-    o, _ = mlp_forward(params, x_test, pb.activation, value_only=True)
+    params = unflatten(flat.astype(dt), pb.layers, pb.net_kind)
+    _, skip, plain = expand_layers(pb.layers, pb.net_kind)
+    o, _ = mlp_forward(params, x_test, pb.activation, value_only=True, skip=skip, plain_tanh=plain)
     u = dt.type(pb.perturb_scale) * o[0]
     if pb.envelope == ENV_SIN:
         u = u * envelope(pb, x_test[:, 0])[0][:, None]

@@ -33,7 +33,23 @@ class ShiftedTanh(nn.Module):
         return torch.tanh(x) + 1.0 + float(np.finfo(float).eps)
 
 
-def build_network(layers, activation: int, dtype=torch.float32) -> nn.Sequential:
+class ResidualBlock(nn.Module):                # box_to_gaussian_pinn_simulation.py:52-62
+    def __init__(self, dim, dtype):
+        super().__init__()
+        self.lin1 = nn.Linear(dim, dim, dtype=dtype)
+        self.lin2 = nn.Linear(dim, dim, dtype=dtype)
+
+    def forward(self, x):
+        return torch.tanh(self.lin2(torch.tanh(self.lin1(x))) + x)
+
+
+def build_network(layers, activation: int, dtype=torch.float32, net_kind: int = 0) -> nn.Sequential:
+    if net_kind == go.NET_RESIDUAL:            # box_to_gaussian_pinn_simulation.py:112-130
+        mods = [nn.Linear(layers[0], layers[1], dtype=dtype), ShiftedTanh() if activation == 1 else nn.Tanh()]
+        for _ in range(len(layers) - 3):
+            mods.append(ResidualBlock(layers[1], dtype))
+        mods.append(nn.Linear(layers[1], layers[-1], dtype=dtype))
+        return nn.Sequential(*mods)
     mods = []
     for i in range(len(layers) - 1):           # harmonic_pinn_simulation.py:84-93
         mods.append(nn.Linear(layers[i], layers[i + 1], dtype=dtype))
@@ -198,7 +214,7 @@ class TorchTrainer:
     def __init__(self, pb: go.Problem, flat: np.ndarray, x: np.ndarray, x_bc=None, lr=1e-3,
                  sched=go.SCHED_CONST, dtype=torch.float32, clip_norm=1.0):
         self.pb = pb
-        self.net = build_network(list(pb.layers), pb.activation, dtype)
+        self.net = build_network(list(pb.layers), pb.activation, dtype, getattr(pb, "net_kind", 0))
         set_flat(self.net, flat)
         self.X = torch.tensor(x, dtype=dtype, requires_grad=True)
         self.x_bc = None if x_bc is None else torch.tensor(x_bc, dtype=dtype)

@@ -74,3 +74,12 @@ def problem_from_paper(fx) -> go.Problem:
     return go.Problem(layers=[int(v) for v in fx["layers"]], activation=0, kinetic_coeff=0.5, potential=go.POT_HARMONIC,
                       pot_scale=0.5, gamma=float(fx["gamma"]), p=int(fx["p"]), abs_power=True, base_mode=0, base_deriv=1,
                       perturb_scale=1.0, w_bc=10.0, w_norm=20.0, w_sym=5.0, w_riesz=1.0, dx=float(fx["dx"]))
+
+
+def problem_from_box2gauss(fx) -> go.Problem:
+    """refine/box_to_gaussian_pinn_simulation.py flavour: residual-block network, sine base on [0, ub], V = exp(-(x - 0.5)^2),
+    -u'' + V u + gamma u^p, forward = network(x) (no boundary factor), 10*bc + 20*norm."""
+    return go.Problem(layers=[int(v) for v in fx["layers"]], net_kind=go.NET_RESIDUAL, activation=1, kinetic_coeff=1.0,
+                      potential=go.POT_GAUSSIAN, pot_a=0.5, gamma=float(fx["gamma"]), p=int(fx["p"]), base_mode=int(fx["mode"]),
+                      base_kind=go.BASE_BOX, box_L=float(fx["ub"]), perturb_scale=float(fx["perturb_const"]) / float(fx["normal_const"]),
+                      bc_nn_scale=1.0, w_bc=10.0, w_norm=20.0, dx=float(fx["dx"]))

@@ -28,7 +28,7 @@ def cfg_from_problem(pb: go.Problem, **kw) -> GPEConfig:
              base_mode=pb.base_mode, base_deriv=pb.base_deriv, perturb_scale=pb.perturb_scale,
              bc_nn_scale=pb.bc_nn_scale, w_pde=pb.w_pde, w_bc=pb.w_bc, w_norm=pb.w_norm, w_sym=pb.w_sym,
              w_orth=pb.w_orth, sym_sign=pb.sym_sign, dx=pb.dx, n_global=pb.n_global, base_kind=pb.base_kind,
-             envelope=pb.envelope, box_L=pb.box_L, env_L=pb.env_L, w_riesz=pb.w_riesz, riesz_kind=pb.riesz_kind)
+             envelope=pb.envelope, box_L=pb.box_L, env_L=pb.env_L, w_riesz=pb.w_riesz, riesz_kind=pb.riesz_kind, net_kind=pb.net_kind)
     d.update(kw)
     return GPEConfig(**d)
 
@@ -89,6 +89,10 @@ CASES = {
                              900, True),
     "3d_riesz_variational": (dict(layers=[3, 128, 128, 128, 1], gamma=100.0, omega=(1.0, 1.4, 2.0), w_riesz=1.0,
                                   riesz_kind=go.RIESZ_VARIATIONAL, dx=0.01), 500, True),
+    # residual-block networks (refine/box_to_gaussian_pinn_simulation.py:52-63,100-130): generic set
+    "1d_residual_64x2blocks": (dict(layers=[1, 64, 64, 64, 1], net_kind=go.NET_RESIDUAL, activation=1, kinetic_coeff=1.0,
+                                    potential=go.POT_GAUSSIAN, pot_a=0.5, gamma=3.0, p=4, base_mode=1, perturb_scale=0.05, dx=0.03), 333, False),
+    "2d_residual_128x3blocks": (dict(layers=[2, 128, 128, 128, 128, 1], net_kind=go.NET_RESIDUAL, gamma=20.0, dx=0.01), 300, False),
     "2d_100x2_odd_width": (dict(layers=[2, 100, 100, 1], gamma=1.0, dx=0.01), 77, False),
     "1d_single_hidden": (dict(layers=[1, 64, 1], gamma=1.0, dx=0.01, base_mode=1), 50, False),
 }
@@ -106,7 +110,7 @@ def _inputs(kw, N, seed=0, scale=0.3):
     d = layers[0]
     x = np.linspace(-6, 6, N).reshape(-1, 1) if d == 1 else rng.uniform(-3, 3, (N, d))
     x = x.astype(np.float32)
-    flat = (rng.normal(0, 1, go.param_count(layers)) * scale).astype(np.float32)
+    flat = (rng.normal(0, 1, go.param_count(layers, kw.get("net_kind", 0))) * scale).astype(np.float32)
     x_bc = (np.array([[-6.0], [6.0]]) if d == 1 else rng.uniform(-3, 3, (5, d))).astype(np.float32)
     return x, flat, x_bc
 
@@ -138,7 +142,9 @@ def test_step_matches_oracle(name, path):
     if path == "fused" and name in PENDING_FUSED:
         pytest.skip("no fused kernel for this shape yet (generic set covers it)")
     osc, ograd, ores = go.full_loss_and_grad(pb, flat.astype(np.float64), x.astype(np.float64), x_bc.astype(np.float64))
-    ojets, _ = go.mlp_forward(go.unflatten(flat.astype(np.float64), pb.layers), x.astype(np.float64), pb.activation)
+    _, oskip, oplain = go.expand_layers(pb.layers, pb.net_kind)
+    ojets, _ = go.mlp_forward(go.unflatten(flat.astype(np.float64), pb.layers, pb.net_kind), x.astype(np.float64), pb.activation,
+                              skip=oskip, plain_tanh=oplain)
     eng = make_engine(pb, flat, x, x_bc, path=PATHS[path])
     assert eng.active_path == PATHS[path]
     jets = eng.forward_jets(torch.as_tensor(x, device="cuda")).cpu().numpy()
@@ -786,3 +792,33 @@ def test_fused_and_generic_agree_at_per_gpu_size(name):
     assert abs(a["mu"] - b["mu"]) < 1e-5 * abs(a["mu"])
     assert abs(a["loss"] - b["loss"]) < 1e-4 * abs(a["loss"])
     assert H.rel_err(gb, ga) < 3e-4
+
+
+# ---- row f3: residual-block network flavour against numbers from the reference's own class (tests/golden/make_golden_box2gauss.py) ----
+@pytest.mark.parametrize("name", ["fx_box2gauss_m0_g0.npz", "fx_box2gauss_m1_g5_p4.npz"])
+def test_golden_box_to_gaussian_residual_network(name):
+    fx = H.load_fx(name)
+    pb = H.problem_from_box2gauss(fx)
+    xb = np.array([[float(fx["lb"])], [float(fx["ub"])]])
+    eng = make_engine(pb, fx["flat0"], fx["x"], xb)
+    assert eng.active_path == gpe_pinn.PATH_GENERIC
+    fwd = eng.forward(torch.as_tensor(fx["x"], device="cuda")).cpu().numpy()
+    assert H.rel_err(fwd, fx["forward_out"]) < 1e-5
+    jets = eng.forward_jets(torch.as_tensor(fx["x"], device="cuda")).cpu().numpy()
+    s = pb.perturb_scale
+    base = go.base_functions(pb, fx["x"][:, 0].astype(np.float64))
+    assert H.rel_err(s * jets[1][:, 0] + base[1], fx["u_x"][:, 0]) < 1e-5 and H.rel_err(s * jets[2][:, 0] + base[2], fx["u_xx"][:, 0]) < 1e-4
+    rs, psi, res = eng.residual()
+    assert H.rel_err(psi.cpu().numpy(), fx["u"]) < 2e-6
+    assert abs(rs["mu"] - float(fx["lam"])) < 5e-5 * abs(float(fx["lam"]))
+    sc = eng.step()
+    assert abs(sc["loss"] - float(fx["total"])) < 1e-3 * float(fx["total"])
+    osc, ograd, _ = go.full_loss_and_grad(pb, fx["flat0"].astype(np.float64), fx["x"].astype(np.float64), xb)
+    assert H.rel_err(eng.get_grad(), ograd) < 5e-5
+    assert H.rel_err(eng.get_grad(), fx["grad0"]) < 1e-3
+    eng.close()
+    # the class surface: same state_dict keys as the reference's nn.Sequential of ResidualBlocks
+    from gpe_pinn import box_to_gaussian as b2g
+    m = b2g.GrossPitaevskiiPINN([int(v) for v in fx["layers"]], mode=int(fx["mode"]), gamma=float(fx["gamma"]), L=float(fx["ub"]))
+    assert list(m.state_dict().keys()) == [str(k) for k in fx["state_dict_keys"]]
+    m.close()

@@ -279,3 +279,22 @@ def test_refine_driver_against_reference_run(name):
                 assert 0.2 * ref_loss[0] <= h["loss"][0] <= 5.0 * ref_loss[0]
             sd = models[mode][g].state_dict()
             assert [tuple(v.shape) for v in sd.values()] == [s for k in range(len(layers) - 1) for s in ((layers[k + 1], layers[k]), (layers[k + 1],))]
+
+
+def test_box_to_gaussian_driver_known_answer():
+    """refine/box_to_gaussian_pinn_simulation.py's driver on the residual-block network: gamma = 0 eigenvalue of -u'' + exp(-(x-1/2)^2) u
+    on [0, 1] is pi^2 + <V> + O(1e-3) = 10.75 (first-order perturbation theory: int 2 sin^2(pi x) exp(-(x-1/2)^2) dx = 0.8821...)."""
+    from gpe_pinn import box_to_gaussian as b2g
+    torch.manual_seed(0)
+    N = 400
+    X = np.linspace(0.0, 1.0, N).reshape(-1, 1)
+    models, mu_table, hist, const, ep = b2g.train_gpe_model([0.0, 1.0], [0], 3, X, 0.0, 1.0, [1, 64, 64, 64, 1], 300, 1e-5, 0.01,
+                                                            potential_type="gaussian", lr=1e-3, verbose=False)
+    xs = np.linspace(0, 1, 20001)
+    first_order = np.pi ** 2 + np.trapezoid(2 * np.sin(np.pi * xs) ** 2 * np.exp(-(xs - 0.5) ** 2), xs)
+    assert abs(mu_table[0][0][1] - first_order) < 2e-2
+    assert mu_table[0][1][1] > mu_table[0][0][1] + 1.0           # gamma = 1 raises lambda by ~ int phi^4 = 1.5
+    sd = models[0][1.0].state_dict()
+    assert list(sd.keys())[2] == "network.2.lin1.weight" and sd["network.3.lin2.weight"].shape == (64, 64)
+    with pytest.raises(ValueError):
+        b2g.train_gpe_model([0.0], [0], 3, X, 0.0, 1.0, [1, 64, 64, 64, 1], 5, 1e-5, 0.01, potential_type="harmonic")

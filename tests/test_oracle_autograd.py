@@ -32,6 +32,9 @@ CASES = {
     "2d_riesz_paper": (dict(layers=[2, 12, 12, 1], gamma=10.0, w_riesz=1.0, riesz_kind=go.RIESZ_PAPER, dx=0.02), 30),
     "1d_shifted_beta_trap": (dict(layers=[1, 16, 16, 1], activation=1, kinetic_coeff=1.0, pot_scale=0.35, omega=(3.0, 1.0, 1.0), pot_a=0.7,
                                   gamma=4.0, dx=0.1), 40),
+    "1d_residual_box_gauss": (dict(layers=[1, 16, 16, 16, 1], net_kind=go.NET_RESIDUAL, activation=1, kinetic_coeff=1.0, potential=go.POT_GAUSSIAN,
+                                   pot_a=0.5, gamma=3.0, p=4, base_mode=1, perturb_scale=0.05, dx=0.02), 40),
+    "2d_residual_3blocks": (dict(layers=[2, 12, 12, 12, 12, 1], net_kind=go.NET_RESIDUAL, gamma=20.0, dx=0.02), 30),
     "1d_gauss": (dict(layers=[1, 12, 12, 1], potential=go.POT_GAUSSIAN, pot_a=0.3, gamma=1.0, dx=0.1), 25),
     "1d_periodic": (dict(layers=[1, 12, 12, 1], potential=go.POT_PERIODIC, gamma=1.0, dx=0.1), 25),
 }
@@ -41,7 +44,7 @@ def _inputs(kw, N, seed=0):
     rng = np.random.default_rng(seed)
     d = kw["layers"][0]
     x = np.linspace(-3, 3, N).reshape(-1, 1) if d == 1 else rng.uniform(-2.5, 2.5, (N, d))
-    flat = rng.normal(0, 1, go.param_count(kw["layers"])) * 0.4
+    flat = rng.normal(0, 1, go.param_count(kw["layers"], kw.get("net_kind", 0))) * 0.4
     x_bc = np.array([[-3.0], [3.0]]) if d == 1 else rng.uniform(-2.5, 2.5, (5, d))
     orth = None
     if kw.get("w_orth", 0.0) != 0.0:
@@ -57,7 +60,7 @@ def test_oracle_matches_autograd_fp64(name, detach):
     x, flat, x_bc, orth = _inputs(kw, N)
     pb = go.Problem(**kw)
     osc, ograd, ores = go.full_loss_and_grad(pb, flat, x, x_bc, orth=orth)
-    net = tr.build_network(list(pb.layers), pb.activation, torch.float64)
+    net = tr.build_network(list(pb.layers), pb.activation, torch.float64, pb.net_kind)
     tr.set_flat(net, flat)
     X = torch.tensor(x, dtype=torch.float64, requires_grad=True)
     total, pieces = tr.epoch_losses(pb, net, X, torch.tensor(x_bc, dtype=torch.float64), detach_lambda=detach,

@@ -242,3 +242,24 @@ def test_advanced_initialization_bit_exact():
         flavour = surface.refine if "refine" in name else surface.notebook
         flat = surface.seeded_reference_init(layers, mode, flavour.KIND)
         np.testing.assert_array_equal(flat, fx["flat0"], err_msg=name)
+
+
+# ---- row f3: residual-block network of refine/box_to_gaussian_pinn_simulation.py (tests/golden/make_golden_box2gauss.py) ------------
+@pytest.mark.parametrize("name", ["fx_box2gauss_m0_g0.npz", "fx_box2gauss_m1_g5_p4.npz"])
+def test_box_to_gaussian_residual_network_oplevel(name):
+    fx = H.load_fx(name)
+    pb = H.problem_from_box2gauss(fx)
+    x = fx["x"].astype(np.float64)
+    flat = fx["flat0"].astype(np.float64)
+    assert flat.size == go.param_count(pb.layers, pb.net_kind)
+    _, skip, plain = go.expand_layers(pb.layers, pb.net_kind)
+    out, _ = go.mlp_forward(go.unflatten(flat, pb.layers, pb.net_kind), x, pb.activation, skip=skip, plain_tanh=plain)
+    assert H.rel_err(out[0], fx["forward_out"]) < 1e-5
+    h = go.head_pde(pb, x, out)
+    assert H.rel_err(h["U"][0], fx["u"]) < 2e-6 and H.rel_err(h["U"][1], fx["u_x"]) < 1e-5 and H.rel_err(h["U"][2], fx["u_xx"]) < 1e-4
+    assert H.rel_err(h["V"][:, None], fx["V"]) < 1e-6
+    sc, grad, _ = go.full_loss_and_grad(pb, flat, x, np.array([[float(fx["lb"])], [float(fx["ub"])]]))
+    assert abs(sc["mu"] - float(fx["lam"])) < 5e-5 * abs(float(fx["lam"]))
+    assert abs(sc["pde"] - float(fx["pde_loss"])) < 1e-3 * float(fx["pde_loss"])
+    assert abs(sc["loss"] - float(fx["total"])) < 1e-3 * float(fx["total"])
+    assert H.rel_err(grad, fx["grad0"]) < 1e-3
