@@ -144,7 +144,7 @@ def cpu_baseline(wl, flat, budget_s=12.0, n_sample=8192):
                        f"thread sweep {sweep}")
 
 
-def cpu_baseline_native(wl, flat, budget_s=10.0, n_sample=32768):
+def cpu_baseline_native(wl, flat, budget_s=12.0, n_sample=262144):
     """The like-for-like algorithm on the host: oracle/cpu_ref (C++/OpenMP forward-mode jets + hand-derived reverse pass, fp32),
     thread sweep {1, all cores}.  Checker-side code (oracle/): timed here, never shipped."""
     try:
@@ -158,17 +158,20 @@ def cpu_baseline_native(wl, flat, budget_s=10.0, n_sample=32768):
     pb = oracle_problem(wl, dx)
     ncpu = os.cpu_count() or 1
     out = {}
-    for nt in sorted({1, ncpu}):
-        cpu_ref.step(lib, pb, flat, xs, threads=nt)           # warm-up
+    sweep = sorted({1, min(16, ncpu), min(64, ncpu), ncpu})
+    for nt in sweep:
+        ns = n_sample if nt > 1 else n_sample // 8           # one thread: a shorter slice of the same points
+        xt = xs[:ns]
+        cpu_ref.step(lib, pb, flat, xt, threads=nt)          # warm-up
         t0 = time.perf_counter()
         n = 0
         while True:
-            cpu_ref.step(lib, pb, flat, xs, threads=nt)
+            cpu_ref.step(lib, pb, flat, xt, threads=nt)
             n += 1
             el = time.perf_counter() - t0
-            if el > budget_s / 2 or n >= 400:
+            if el > budget_s / len(sweep) or n >= 400:
                 break
-        out[nt] = n * n_sample / el
+        out[nt] = n * ns / el
     best_nt = max(out, key=out.get)
     return dict(value=out[best_nt], unit="points/s", cores=int(best_nt), kind="native", host_cpus=int(ncpu),
                 per_threads={str(k): v for k, v in out.items()},
@@ -304,10 +307,18 @@ def main():
         traffic, traffic_src, util = None, None, None
         tj, tsrc = load_profile_json(f"traffic_{args.workload}.json")
         if tj:
-            for k, v in tj.get("kernels", {}).items():
-                if ("f_backward" in k or "bwd" in k) and (traffic is None or v["hbm_bytes_per_point"] * n_rows > traffic):
-                    traffic = v["hbm_bytes_per_point"] * n_rows
-                    traffic_src = f"from_profile: {tsrc} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 1/2-fetch correction)"
+            ks = tj.get("kernels", {})
+            if "w_bwd_map" in kernels["bwd"]:       # the reverse pass is several launches: bytes of ONE pass = sum over its launches
+                fwd_n = max([v["dispatches"] for k, v in ks.items() if "w_forward" in k] or [0])
+                tot = sum(v["hbm_bytes_per_point"] * v["dispatches"] for k, v in ks.items() if "w_bwd" in k)
+                if fwd_n:
+                    traffic = tot / fwd_n * n_rows
+            else:
+                for k, v in ks.items():
+                    if "f_backward" in k and (traffic is None or v["hbm_bytes_per_point"] * n_rows > traffic):
+                        traffic = v["hbm_bytes_per_point"] * n_rows
+            if traffic is not None:
+                traffic_src = f"from_profile: {tsrc} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 1/2-fetch correction)"
         uj, usrc = load_profile_json(f"mfma_util_{args.workload}.json")
         if uj:
             util = dict(uj, source=f"from_profile: {usrc}")
@@ -331,7 +342,8 @@ def main():
                          "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP32_MFMA_PEAK_TFLOPS, "frac_gemm_only": ach_gemm / FP32_MFMA_PEAK_TFLOPS,
                          "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": (bmat_pt / 2.0 * (Lh - 1) / Lh + 4.0 * chan * layers[-1] + 4.0 * d_in) * n_rows,
+                         "algorithmic_bytes_per_launch": ((bmat_pt / 2.0 * (Lh - 1) / Lh + 4.0 * chan * layers[-1] + 4.0 * d_in) if "w_bwd_map" not in kernels["bwd"]
+                                                          else (4.0 * chan * Hh * (3 * Lh - 5) + 4.0 * chan * layers[-1] + 4.0 * d_in)) * n_rows,
                          "algorithmic_flop_per_point": 2.0 * f_fwd, "gemm_flop_per_point": 2.0 * gemm_fwd,
                          "rows_per_launch": n_rows, "avg_launch_ms": bwd_s * 1e3, "launches": prof["bwd_launches"],
                          "counters": util},
