@@ -215,6 +215,8 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--exchange", default="engine", choices=["engine", "torch"],
                     help="N > 1: all-reduces issued by the engine (native RCCL) or by torch.distributed between the phases")
+    ap.add_argument("--async-grad", action="store_true",
+                    help="OPT-IN one-step-stale gradient: the gradient all-reduce overlaps the next forward (changes the trajectory; labelled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -254,6 +256,8 @@ def main():
     native = use_dist and args.exchange == "engine"
     if native:
         eng.comm_init(rank, world)
+        if args.async_grad:
+            eng.comm_set_async(True)
 
     def run_steps(k):
         if not use_dist:
@@ -331,7 +335,7 @@ def main():
             "config": {"workload": args.workload, "layers": layers, "points_per_gpu": n_local,
                        "global_points": n_local * world, "gamma": wl["gamma"], "boundary_points": int(xb.shape[0]),
                        "parallelism": f"dp{world}", "kernel_path": "fused_mfma_f32_16x16x4" if fused else "generic_layerwise_mfma",
-                       "exchange": ("engine_rccl" if native else "torch_distributed") if use_dist else "none"},
+                       "exchange": (("engine_rccl_stale1" if args.async_grad else "engine_rccl") if native else "torch_distributed") if use_dist else "none"},
             "per_gpu_points_per_s": value / world,
             "rccl_ranks": comm["world"] if native else (world if use_dist else 0),
             "collectives_per_step": (comm["collectives"] / max(1, args.steps + args.warmup)) if native else (2 if use_dist else 0),

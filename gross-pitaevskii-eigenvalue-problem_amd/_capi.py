@@ -76,6 +76,7 @@ SYMBOLS = {
     "gpe_comm_init": (_int, [_vp, _vp, _int, _int]),
     "gpe_comm_destroy": (_int, [_vp]),
     "gpe_comm_info": (_int, [_vp, _P(_int), _P(_int), _P(_i64)]),
+    "gpe_comm_set_async": (_int, [_vp, _int]),
     "gpe_step_dp": (_int, [_vp]),
     "gpe_run_dp": (_int, [_vp, _i64]),
     "gpe_param_count": (_i64, [_vp]),

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(1024) void k_update(int P, float* __restrict__ thet
                                                   gpe_scalars* __restrict__ hist, int cap, gpe_scalars* __restrict__ last,
                                                   double bc_cnt, int do_update, int mse_mode, NetDesc nd, int H,
                                                   float* __restrict__ Wpk, float* __restrict__ WpkT, int n_pack,
-                                                  double* __restrict__ dbl, int n_dbl) {
+                                                  double* __restrict__ dbl, int n_dbl, double* __restrict__ dbl_keep) {
     __shared__ double red[16];
     __shared__ float s_coef, s_ss, s_b2s;
     __shared__ int s_skip, s_book, s_frozen;
@@ -179,7 +179,8 @@ __global__ __launch_bounds__(1024) void k_update(int P, float* __restrict__ thet
     // Prepare the NEXT step, so that it can start with its forward kernel: the step sums are consumed (thread 0 read them
     // before the barrier above) -> zero them; repack the hidden-hidden weights in MFMA fragment order from the new parameters.
     __syncthreads();
-    for (int i = threadIdx.x; i < n_dbl; i += 1024) dbl[i] = 0.0;
+    // (stale-gradient mode: this step's sums are kept for the NEXT update, which applies this step's gradient)
+    for (int i = threadIdx.x; i < n_dbl; i += 1024) { if (dbl_keep) dbl_keep[i] = dbl[i]; dbl[i] = 0.0; }
     for (int i = threadIdx.x; i < n_pack; i += 1024) pack_weight_element(nd, H, theta, Wpk, WpkT, i);
 }
 
@@ -284,6 +285,13 @@ struct gpe_engine {
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_x0 = nullptr, ev_x1 = nullptr;      // compute -> exchange, exchange -> compute
     std::vector<hipEvent_t> ev_bucket;                // one per linear map: its gradient slice is final
+    // opt-in one-step-stale gradient (gpe_comm_set_async): the all-reduce of g_t runs on the exchange stream behind the forward of
+    // step t+1, whose update applies g_t; changes the trajectory -- never on by default
+    bool async_grad = false;
+    float* grad_alt = nullptr;                        // second gradient buffer (P + GT_COUNT)
+    double* dbl_prev = nullptr;                       // sums of the step whose gradient is in flight
+    hipEvent_t ev_g[2] = {nullptr, nullptr};
+    int64_t async_t = 0;
     bool dp_bucket = false;                           // set by gpe_step_dp: the generic reverse pass hands finished layers to the comm stream
     int64_t dp_collectives = 0;                       // all-reduces issued since gpe_comm_init (bench / tests)
     int phase = 0;                 // 0 idle, 1 after begin, 2 after backward
@@ -1412,7 +1420,7 @@ int gpe_step_backward(gpe_engine* e) {
 
 // trailing arguments of k_update: what it needs to prepare the next step (weight packing on the fused path, sum zeroing)
 #define UPD_TAIL_ARGS e->nd, e->H, e->Wpk, e->WpkT, (e->path == GPE_PATH_FUSED ? (e->nd.n_lin - 2) * e->H * e->H : 0), e->dbl, \
-                      (int)(S_COUNT + LS_COUNT + 4)
+                      (int)(S_COUNT + LS_COUNT + 4), (double*)nullptr
 static void after_update(gpe_engine* e) {          // host-side mirror of what k_update left behind
     e->acc_clean = true;
     e->packed_dirty = false;
@@ -1560,6 +1568,10 @@ int gpe_comm_destroy(gpe_engine* e) {
     (void)hipEventDestroy(e->ev_x0); (void)hipEventDestroy(e->ev_x1); e->ev_x0 = e->ev_x1 = nullptr;
     for (hipEvent_t ev : e->ev_bucket) (void)hipEventDestroy(ev);
     e->ev_bucket.clear();
+    for (auto& ev : e->ev_g) { if (ev) (void)hipEventDestroy(ev); ev = nullptr; }
+    if (e->grad_alt) { (void)hipFree(e->grad_alt); e->grad_alt = nullptr; }
+    if (e->dbl_prev) { (void)hipFree(e->dbl_prev); e->dbl_prev = nullptr; }
+    e->async_grad = false;
     return GPE_OK;
 }
 
@@ -1588,9 +1600,72 @@ static int dp_join(gpe_engine* e) {       // the compute stream continues after 
 // One synchronous data-parallel step, no host synchronisation: begin -> all-reduce of the 12 double sums -> backward with the
 // gradient all-reduced on the exchange stream (generic set: one bucket per linear map, output map first, behind the remaining
 // reverse pass; fused set: the reverse pass is a single kernel, so one P+4 message) -> clip/Adam (replicated, bit-identical).
+// One-step-stale variant (gpe_comm_set_async).  Step t: forward / sums exchange / reverse with theta_t -> g_t; its all-reduce is
+// issued on the exchange stream and NOT waited for; the update of step t applies g_{t-1} (all-reduced while step t computed) with
+// the scalars of step t-1.  Step 0 applies nothing.  Records (gpe_read_scalars, history) therefore lag one step.
+static int step_dp_async(gpe_engine* e) {
+    int rc;
+    const int cur = (int)(e->async_t & 1), prv = cur ^ 1;
+    float* bufs[2] = {e->grad, e->grad_alt};          // e->grad alternates between the two
+    float* gcur = (e->async_t & 1) ? e->grad_alt : e->grad;
+    (void)bufs;
+    float* const g_home = e->grad;
+    e->grad = gcur;                                   // this step's buffer: zeroed by k_begin (generic set), written by the reverse pass;
+                                                      // the other one holds g_{t-1} until this step's update has applied it
+    e->acc_clean = e->acc_clean && e->path == GPE_PATH_FUSED;
+    rc = gpe_step_begin(e);
+    if (!rc) rc = dp_allreduce_after(e, e->sums(), S_COUNT, ncclDouble, e->ev_x0);
+    if (!rc) rc = dp_join(e);
+    if (!rc) rc = gpe_step_backward(e);
+    if (!rc) {
+        hipError_t st;
+        if ((st = hipEventRecord(e->ev_x0, e->stream)) != hipSuccess || (st = hipStreamWaitEvent(e->comm_stream, e->ev_x0, 0)) != hipSuccess) {
+            e->grad = g_home;
+            FAIL(e, GPE_ERR_HIP, "stale-gradient exchange: %s", hipGetErrorString(st));
+        }
+        ncclResult_t nr = e->rccl.AllReduce(gcur, gcur, (size_t)e->P + GT_COUNT, ncclFloat, ncclSum, e->comm, e->comm_stream);
+        if (nr != ncclSuccess) { e->grad = g_home; FAIL(e, GPE_ERR_HIP, "ncclAllReduce: %s", e->rccl.GetErrorString(nr)); }
+        e->dp_collectives++;
+        (void)hipEventRecord(e->ev_g[cur], e->comm_stream);
+    }
+    e->grad = g_home;
+    if (rc) return rc;
+    float* gprev = (prv == 1) ? e->grad_alt : e->grad;
+    const int apply = e->async_t > 0;
+    HIPCHK(e, hipStreamWaitEvent(e->stream, e->ev_g[apply ? prv : cur], 0));     // step 0 only records: it reads its own (reduced) tail
+    hipLaunchKernelGGL(k_update, dim3(1), dim3(1024), 0, e->stream, e->P, e->theta, e->am, e->av, apply ? gprev : gcur,
+                       apply ? (const double*)e->dbl_prev : (const double*)e->sums(),
+                       apply ? (const double*)(e->dbl_prev + S_COUNT) : (const double*)e->lsums(), e->ph, e->oc, e->od, e->hist, e->cap,
+                       e->last, bc_count(e), apply, 0, e->nd, e->H, e->Wpk, e->WpkT,
+                       (e->path == GPE_PATH_FUSED ? (e->nd.n_lin - 2) * e->H * e->H : 0), e->dbl, (int)(S_COUNT + LS_COUNT + 4), e->dbl_prev);
+    HIPCHK(e, hipGetLastError());
+    after_update(e);
+    e->phase = 0;
+    e->async_t++;
+    return GPE_OK;
+}
+
+int gpe_comm_set_async(gpe_engine* e, int on) {
+    if (!e) return GPE_ERR_INVALID;
+    if (!e->comm) FAIL(e, GPE_ERR_STATE, "gpe_comm_set_async before gpe_comm_init");
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->comm_stream));
+    if (on && !e->grad_alt) {
+        HIPCHK(e, hipMalloc((void**)&e->grad_alt, ((size_t)e->P + GT_COUNT) * sizeof(float) + 256));
+        HIPCHK(e, hipMalloc((void**)&e->dbl_prev, (S_COUNT + LS_COUNT + 4) * sizeof(double) + 256));
+        HIPCHK(e, hipMemset(e->grad_alt, 0, ((size_t)e->P + GT_COUNT) * sizeof(float)));
+        HIPCHK(e, hipMemset(e->dbl_prev, 0, (S_COUNT + LS_COUNT + 4) * sizeof(double)));
+        for (auto& ev : e->ev_g) HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    e->async_grad = on != 0;
+    e->async_t = 0;
+    return GPE_OK;
+}
+
 int gpe_step_dp(gpe_engine* e) {
     if (!e) return GPE_ERR_INVALID;
     if (!e->comm) FAIL(e, GPE_ERR_STATE, "gpe_step_dp before gpe_comm_init");
+    if (e->async_grad) return step_dp_async(e);
     int rc;
     if ((rc = gpe_step_begin(e))) return rc;
     if ((rc = dp_allreduce_after(e, e->sums(), S_COUNT, ncclDouble, e->ev_x0))) return rc;

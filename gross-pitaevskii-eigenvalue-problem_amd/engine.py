@@ -207,6 +207,10 @@ class Engine:
     def comm_destroy(self):
         self._chk(self.lib.gpe_comm_destroy(self._h))
 
+    def comm_set_async(self, on: bool = True):
+        """OPT-IN one-step-stale gradient (gradient all-reduce overlapped with the next forward); changes the trajectory."""
+        self._chk(self.lib.gpe_comm_set_async(self._h, int(on)))
+
     def step_dp(self):
         """One data-parallel step with both exchanges issued by the engine (no Python between the phases, no host sync)."""
         self._chk(self.lib.gpe_step_dp(self._h))

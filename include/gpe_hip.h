@@ -213,6 +213,11 @@ int gpe_comm_destroy(gpe_engine* e);
 int gpe_comm_info(const gpe_engine* e, int* rank, int* world, int64_t* collectives);   /* rank -1 / world 0: no communicator */
 int gpe_step_dp(gpe_engine* e);
 int gpe_run_dp(gpe_engine* e, int64_t n_steps);
+/* OPT-IN one-step-stale gradient: the all-reduce of step t's gradient stays in flight on the exchange stream behind the forward
+ * of step t+1; the update of step t applies the (all-reduced) gradient and scalars of step t-1, step 0 applies nothing, records lag
+ * one step.  It changes the optimisation trajectory -- not comparable bit for bit with the reference -- and is never enabled
+ * implicitly; a run that uses it must say so. */
+int gpe_comm_set_async(gpe_engine* e, int on);
 /* all three phases + synchronise + scalars (single rank) */
 int gpe_step(gpe_engine* e, gpe_scalars* out);
 /* n steps enqueued back to back, no host synchronisation (single rank) */

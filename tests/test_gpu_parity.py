@@ -822,3 +822,35 @@ def test_golden_box_to_gaussian_residual_network(name):
     m = b2g.GrossPitaevskiiPINN([int(v) for v in fx["layers"]], mode=int(fx["mode"]), gamma=float(fx["gamma"]), L=float(fx["ub"]))
     assert list(m.state_dict().keys()) == [str(k) for k in fx["state_dict_keys"]]
     m.close()
+
+
+@pytest.mark.parametrize("path", ["generic", "fused"])
+def test_stale_gradient_mode_is_the_one_step_delayed_trajectory(path):
+    """gpe_comm_set_async (opt-in): theta_{t+1} = Adam(theta_t, g(theta_{t-1})), step 0 applies nothing.  Emulated with the oracle:
+    same clip / Adam, gradients taken one step late.  (World 1 through the native communicator: the code path of N ranks.)"""
+    kw = dict(layers=[2, 64, 64, 64, 1], gamma=50.0, dx=0.01)
+    x, flat, x_bc = _inputs(kw, 1500)
+    pb = go.Problem(**kw)
+    eng = make_engine(pb, flat, x, x_bc, path=PATHS[path])
+    eng.comm_init(0, 1)
+    eng.comm_set_async(True)
+    K = 5
+    for _ in range(K):
+        eng.step_dp()
+    eng.synchronize()
+    got = eng.get_params()
+    theta = flat.copy()
+    st = go.OptState(lr0=1e-3)
+    pend = None
+    for t in range(K):
+        sc, g, _ = go.full_loss_and_grad(pb, theta.astype(np.float64), x.astype(np.float64), x_bc.astype(np.float64))
+        if pend is not None:
+            theta, _, _ = go.optimizer_step(st, theta, pend[0], pend[1])
+        pend = (g, sc["loss"])
+    assert np.abs(got - theta).max() < 5e-5, np.abs(got - theta).max()
+    # and it differs from the synchronous trajectory (which applies K updates, not K - 1)
+    ref = make_engine(pb, flat, x, x_bc, path=PATHS[path])
+    for _ in range(K):
+        ref.step()
+    assert np.abs(ref.get_params() - got).max() > 1e-4
+    eng.close(); ref.close()
