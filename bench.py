@@ -226,6 +226,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("GPE_BENCH_LAUNCH_TEST"):            # CPU test of the launcher: report the rank environment, touch nothing
+        print(json.dumps({"launch_test": True, "rank": rank, "local_rank": local_rank, "world": world,
+                          "master": os.environ.get("MASTER_ADDR"), "gpus_arg": args.gpus}), flush=True)
+        return
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or "RANK" in os.environ          # under torchrun always take the RCCL path, even at world 1

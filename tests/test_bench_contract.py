@@ -28,6 +28,50 @@ def test_workloads_are_consistent():
         assert flat.shape == (n_par,) and np.isfinite(flat).all()
 
 
+def test_gpus_n_launches_n_ranks():
+    """`python bench.py --gpus N` without RANK in the environment starts N worker processes (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set) before anything touches the GPU; with RANK set (torchrun) it is itself a worker."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["GPE_BENCH_LAUNCH_TEST"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "2"], capture_output=True, text=True,
+                         timeout=300, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    recs = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert sorted(r["rank"] for r in recs) == [0, 1, 2] and all(r["world"] == 3 and r["local_rank"] == r["rank"] for r in recs)
+    assert all(r["master"] == "127.0.0.1" and r["gpus_arg"] == 3 for r in recs)
+    env2 = dict(env, RANK="1", LOCAL_RANK="1", WORLD_SIZE="2")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300,
+                         cwd=ROOT, env=env2)
+    recs = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(recs) == 1 and recs[0]["rank"] == 1 and recs[0]["world"] == 2      # no second launch under torchrun
+
+
+def test_strong_scaling_splits_the_baseline_global_grid():
+    import bench
+    for name in ("ns_2d_4x64", "cfg3_2d_5x128", "cfg5_3d_6x256"):
+        wl = bench.WORKLOADS[name]
+        tot = int(np.prod(wl["global_grid"]))
+        parts = [bench.make_points(wl, r, 8, "strong") for r in range(8)]
+        assert sum(p[0].shape[0] for p in parts) == tot
+        assert all(abs(p[1] - parts[0][1]) < 1e-12 for p in parts)                           # one quadrature weight
+        xs = np.concatenate([p[0][:, 0] for p in parts])
+        assert np.all(np.diff(xs[::parts[0][0].shape[0] // wl["global_grid"][0] or 1]) >= -1e-6)   # blocks ordered along the first axis
+    g3 = bench.make_points(bench.WORKLOADS["cfg3_2d_5x128"], 0, 8, "strong")[0].shape[0]
+    assert g3 == 131072                                                                          # BASELINE configs[2]: 1 048 576 / 8
+
+
+@pytest.mark.gpu
+def test_bench_native_exchange_path_world_1():
+    """RANK set (as under torchrun): torch.distributed(nccl) for the rendezvous + the engine's own RCCL communicator for the data path."""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cfg2_1d_4x64", "--steps", "3", "--warmup", "1",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["config"]["exchange"] == "engine_rccl" and d["rccl_ranks"] == 1 and d["n_gpus"] == 1
+    assert abs(d["collectives_per_step"] - 2.0) < 1e-9
+
+
 @pytest.mark.gpu
 def test_bench_line_contract():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cfg2_1d_4x64", "--steps", "3", "--warmup", "1",
