@@ -1606,9 +1606,7 @@ static int dp_join(gpe_engine* e) {       // the compute stream continues after 
 static int step_dp_async(gpe_engine* e) {
     int rc;
     const int cur = (int)(e->async_t & 1), prv = cur ^ 1;
-    float* bufs[2] = {e->grad, e->grad_alt};          // e->grad alternates between the two
-    float* gcur = (e->async_t & 1) ? e->grad_alt : e->grad;
-    (void)bufs;
+    float* gcur = (e->async_t & 1) ? e->grad_alt : e->grad;       // the two gradient buffers alternate
     float* const g_home = e->grad;
     e->grad = gcur;                                   // this step's buffer: zeroed by k_begin (generic set), written by the reverse pass;
                                                       // the other one holds g_{t-1} until this step's update has applied it

@@ -101,7 +101,13 @@ for si, g in enumerate(gam):
         eng.set_loss_weights(1.0, a.w_bc, a.w_norm_final, 0.0, 0.0, a.w_riesz)
         for frac, lr in ((0.35, a.lr), (0.2, a.lr * 0.3), (0.2, a.lr * 0.1), (0.15, a.lr * 0.03), (0.1, a.lr * 0.01)):
             eng.set_lr(lr)
-            eng.run(int(ne * frac))
+            left = int(ne * frac)
+            while left > 0:                       # progress line at least every ~10 000 epochs (a silent GPU job is taken to be hung)
+                n_run = min(left, 10000)
+                eng.run(n_run)
+                left -= n_run
+                scp = eng.read_scalars()
+                print(f"   final stage: lr {lr:.1e} mu {scp['mu']:.6f} pde {scp['pde']:.3e} int {scp['integral']:.6f} ({time.time() - t0:.0f} s)", flush=True)
     sc = eng.read_scalars()
     rows.append(dict(gamma=g, epochs=ne, mu=sc["mu"], loss=sc["loss"], pde=sc["pde"], norm=sc["integral"], lr=sc["lr"], riesz=sc["riesz"]))
     print(f"stage {si}: gamma {g:8.2f} mu {sc['mu']:.6f} E {sc['riesz']:.6f} loss {sc['loss']:.3e} pde {sc['pde']:.3e} int {sc['integral']:.6f} lr {sc['lr']:.1e} "
