@@ -8,8 +8,9 @@
 //                jets of a layer are all-gathered through ONE LDS buffer [C][H/16][256] (80 KB at H = 256, C = 5: two
 //                barriers per layer); the W rows of the wave stream from L2 (packed fragments, double-buffered chunks of 4
 //                K tiles); (t, z_k, z_L) are stored fragment-native exactly as f_forward does.
-//   w_bwd_out    output layer: dW_out, db_out, adjoint + activation adjoint of the last hidden layer -> zbar_{L-1} in HBM
-//                ([tile][C][H/16][256], fragment-native).  VALU only.
+//   w_bwd_out    output layer as a launch of its own: dW_out, db_out, adjoint + activation adjoint of the last hidden layer ->
+//                zbar_{L-1} in HBM ([tile][C][H/16][256], fragment-native).  VALU only.  Kept for GPE_WIDE_TOP=0; by default the
+//                topmost w_bwd_map launch does this work itself (template parameter TOP).
 //   w_bwd_map    ONE hidden->hidden map j per launch, top down:  zbar_j (HBM) -> abar = W_j^T zbar_j (MFMA), activation
 //                adjoint -> zbar_{j-1} (HBM; for j = 1 the layer-0 gradients instead), dW_j += Zbar_j X_{j-1}^T (MFMA) kept in
 //                accumulator registers across all tiles of the workgroup.  The 256 x 256 gradient does not fit 512 lanes
@@ -51,9 +52,6 @@ __device__ unsigned long long w_trace[2][8][16];     // absolute stamps of one i
 #define W_NW 8            // waves per workgroup
 #define W_KC 4            // K tiles per streamed weight chunk (forward)
 #define W_KCB 2           // ... in the reverse map kernel (register budget: 256 with the 64-register gradient block)
-
-template <int H, int C>
-__host__ __device__ constexpr int w_fwd_lds_floats(int small, int nout) { return small + C * (H / 16) * 256 + W_NW * nout * C * 16; }
 
 // ---- forward ---------------------------------------------------------------------------------------------------------------
 #define W_TRACE_K 0

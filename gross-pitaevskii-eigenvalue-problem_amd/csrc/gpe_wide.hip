@@ -82,7 +82,8 @@ static void launch_bwd(const WideCall& a) {
     const size_t lds_m = ((size_t)7 * HH + 4 + small4(a.nd, HH) + (size_t)CC * NT * 256 + (size_t)CC * W_NW * F_TILE) * sizeof(float);
     float* zcur = a.Z0;
     float* znext = a.Z1;
-    static const bool fuse_top = !(getenv("GPE_WIDE_TOP") && atoi(getenv("GPE_WIDE_TOP")) == 0);     // 0: separate w_bwd_out launch
+    const char* envt = getenv("GPE_WIDE_TOP");                 // 0: the output layer as a launch of its own (w_bwd_out)
+    const bool fuse_top = !(envt && atoi(envt) == 0);
     if (!fuse_top) {
         if (no == 1)
             hipLaunchKernelGGL((w_bwd_out<HH, CC, EE, 1, NS>), dim3(grid), dim3(512), lds_o, a.stream, a.nd, a.theta, a.pts, a.stored, a.Ob,

@@ -854,3 +854,23 @@ def test_stale_gradient_mode_is_the_one_step_delayed_trajectory(path):
         ref.step()
     assert np.abs(ref.get_params() - got).max() > 1e-4
     eng.close(); ref.close()
+
+
+def test_wide_set_output_layer_fused_or_separate_agree():
+    """The topmost w_bwd_map launch forms zbar_{L-1}, dW_out, db_out itself (default) or reads what w_bwd_out wrote (GPE_WIDE_TOP=0)."""
+    import os
+    kw, N = CASES["3d_256x6_cfg5_N300"][0], 1100
+    x, flat, x_bc = _inputs(kw, N, scale=_scale(kw))
+    res = []
+    for top in ("1", "0"):
+        old = os.environ.get("GPE_WIDE_TOP")
+        os.environ["GPE_WIDE_TOP"] = top
+        try:
+            eng = make_engine(go.Problem(**kw), flat, x, x_bc, path=gpe_pinn.PATH_FUSED)
+            sc = eng.step()
+            res.append((sc["loss"], eng.get_grad()))
+            eng.close()
+        finally:
+            os.environ.pop("GPE_WIDE_TOP", None) if old is None else os.environ.__setitem__("GPE_WIDE_TOP", old)
+    assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[0][0])
+    assert H.rel_err(res[0][1], res[1][1]) < 3e-6
