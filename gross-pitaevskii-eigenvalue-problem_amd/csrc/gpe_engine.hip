@@ -271,6 +271,7 @@ struct gpe_engine {
     bool merge_bc = true;
     const float* mse_target = nullptr;
     int num_cu = 256;
+    int head_wg_per_cu = 2;        // head / seed kernels: workgroups per CU (each ends in one double atomic per global sum)
     // ---- data-parallel exchange inside the engine: RCCL on a dedicated stream (gpe_comm_init) ----
     struct Rccl {
         void* dl = nullptr;
@@ -1087,6 +1088,8 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
         (void)hipFuncSetAttribute((const void*)g_bwd_weight_mfma2<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)g_bwd_weight_mfma2<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #endif
+        const char* envh = getenv("GPE_HEAD_WG_PER_CU");
+        if (envh && atoi(envh) > 0) e->head_wg_per_cu = atoi(envh);
         const char* envb = getenv("GPE_MERGE_BC");
         e->merge_bc = !envb || atoi(envb) != 0;
         const char* envg = getenv("GPE_GRAPH");
@@ -1313,7 +1316,7 @@ int gpe_eval_density(gpe_engine* e, const float* d_x, int64_t n, float dx, int a
 }
 
 // ---- the step ------------------------------------------------------------------------------------------
-static unsigned head_grid(gpe_engine* e, int64_t n) { return (unsigned)std::min<int64_t>(cdiv(n, 256), (int64_t)e->num_cu * 2); }
+static unsigned head_grid(gpe_engine* e, int64_t n) { return (unsigned)std::min<int64_t>(cdiv(n, 256), (int64_t)e->num_cu * e->head_wg_per_cu); }
 
 static int launch_head_pde(gpe_engine* e) {
     Batch& b = e->main;
