@@ -77,21 +77,28 @@ struct Pts { const float* a; const float* b; long long na; };
 GPE_DEV float pts_at(const Pts& P, long long p, int dim, int k) { return p < P.na ? P.a[p * dim + k] : P.b[(p - P.na) * dim + k]; }
 
 // ------------------------------------------------------------------------------------------------
-// tanh: odd polynomial for |x| < 0.25, 1 - 2/(exp(2|x|)+1) otherwise.  abs error ~1e-7.
+// tanh = 1 - 2/(exp(2x)+1): five instructions (two of them quarter-rate), no branch on |x| -- on gfx950 the fp32 MFMAs and the
+// VALU share the FMA lanes (no co-execution), so every VALU instruction of the activation is time taken from the matrix products.
+// abs error <= 2.5e-7 over the whole line (fp32 round-off of the 1 - 2r form; tests/test_gpu_parity.py::test_tanh_accuracy_through_forward).
 // Shared by both kernel sets so that they agree bit for bit on the activation.
 // ------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+GPE_DEV float gpe_fma(float a, float b, float c) { return fmaf(a, b, c); }
+GPE_DEV f32x4 gpe_fma(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
+
 GPE_DEV float gpe_tanh(float x) {
-    float ax = fabsf(x);
-    float x2 = x * x;
-    // x - x^3/3 + 2x^5/15 - 17x^7/315 + 62x^9/2835
-    float p = fmaf(x2, 0.021869488536155203f, -0.053968253968253971f);
-    p = fmaf(x2, p, 0.13333333333333333f);
-    p = fmaf(x2, p, -0.33333333333333331f);
-    p = fmaf(x2 * x, p, x);
-    float e = __builtin_amdgcn_exp2f(ax * 2.8853900817779268f);   // exp(2|x|) as one v_exp_f32; +inf for large |x| -> r = 1
-    float r = fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);  // v_rcp_f32 (1 ulp)
-    r = copysignf(r, x);
-    return ax < 0.25f ? p : r;
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);   // exp(2x): 0 for very negative x (-> -1), +inf for large x (-> 1)
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);         // v_exp_f32, v_rcp_f32: 1 ulp each
+}
+GPE_DEV f32x4 gpe_tanh(f32x4 x) {                                      // the same per element, the multiplies and adds packed
+    const f32x4 a = x * 2.8853900817779268f;
+    f32x4 e, r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(a[i]);
+    const f32x4 d = e + 1.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = __builtin_amdgcn_rcpf(d[i]);
+    return gpe_fma((f32x4)(-2.0f), r, (f32x4)(1.0f));
 }
 
 // Jet channels.  A batch carries C = 1 + D + E channels per feature: the value, D first derivatives and E second-order
@@ -104,25 +111,27 @@ GPE_DEV float gpe_tanh(float x) {
 // With sigma = tanh:  sigma' = s = 1 - t^2,  sigma'' = w2 = -2 t s,  sigma''' = q = s (4 t^2 - 2 s) = s (4 - 6 s).
 // The expressions below are arranged for the fewest VALU instructions (the compiler may not reassociate fp32): 10 for the
 // jets, 26 for jets + adjoint of a 2D Laplacian batch.  Both kernel sets share them, so they agree bit for bit.
-template <int D, int E>
-GPE_DEV void act_from_stored(float t, const float* zk, const float* zkk, float shift, float* a /*[1+D+E]*/) {
-    const float s = fmaf(-t, t, 1.0f);
-    const float w2 = -2.0f * (t * s);
+// T = float (one element) or f32x4 (the four elements a lane holds of one MFMA tile: packed v_pk_* arithmetic, the same
+// operations in the same order per element, so both forms agree bit for bit).
+template <int D, int E, typename T>
+GPE_DEV void act_from_stored(T t, const T* zk, const T* zkk, float shift, T* a /*[1+D+E]*/) {
+    const T s = gpe_fma(-t, t, (T)(1.0f));
+    const T w2 = -2.0f * (t * s);
     a[0] = t + shift;
     if constexpr (E == D) {
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             a[1 + j] = s * zk[j];
-            a[1 + D + j] = fmaf(w2 * zk[j], zk[j], s * zkk[j]);
+            a[1 + D + j] = gpe_fma(w2 * zk[j], zk[j], s * zkk[j]);
         }
     } else {
         static_assert(E == 1, "second-order channels: one per axis, or the single Laplacian channel");
-        float S = zk[0] * zk[0];
+        T S = zk[0] * zk[0];
 #pragma unroll
-        for (int j = 1; j < D; ++j) S = fmaf(zk[j], zk[j], S);
+        for (int j = 1; j < D; ++j) S = gpe_fma(zk[j], zk[j], S);
 #pragma unroll
         for (int j = 0; j < D; ++j) a[1 + j] = s * zk[j];
-        a[1 + D] = fmaf(w2, S, s * zkk[0]);
+        a[1 + D] = gpe_fma(w2, S, s * zkk[0]);
     }
 }
 
@@ -131,34 +140,34 @@ GPE_DEV void act_from_stored(float t, const float* zk, const float* zkk, float s
 //   zbar_k  = s abar_k + 2 w2 z_k abar_kk
 //   zbar    = s abar + sum_k [ w2 z_k abar_k + (w2 z_kk + q z_k^2) abar_kk ]
 // Laplacian channel: the same with abar_kk -> abar_L for every k, z_kk -> z_L once, z_k^2 -> sum_k z_k^2.
-template <int D, int E>
-GPE_DEV void act_adjoint(float t, const float* zk, const float* zkk, const float* ab /*[1+D+E]*/, float* zb /*[1+D+E]*/) {
-    const float s = fmaf(-t, t, 1.0f);
-    const float w2 = -2.0f * (t * s);
-    const float q = s * fmaf(-6.0f, s, 4.0f);
-    float acc = s * ab[0];
+template <int D, int E, typename T>
+GPE_DEV void act_adjoint(T t, const T* zk, const T* zkk, const T* ab /*[1+D+E]*/, T* zb /*[1+D+E]*/) {
+    const T s = gpe_fma(-t, t, (T)(1.0f));
+    const T w2 = -2.0f * (t * s);
+    const T q = s * gpe_fma((T)(-6.0f), s, (T)(4.0f));
+    T acc = s * ab[0];
     if constexpr (E == D) {
 #pragma unroll
         for (int j = 0; j < D; ++j) {
-            const float akb = ab[1 + j], akkb = ab[1 + D + j];
-            const float wz = w2 * zk[j];
+            const T akb = ab[1 + j], akkb = ab[1 + D + j];
+            const T wz = w2 * zk[j];
             zb[1 + D + j] = s * akkb;
-            zb[1 + j] = fmaf(wz + wz, akkb, s * akb);
-            acc = fmaf(wz, akb, acc);
-            acc = fmaf(fmaf(q * zk[j], zk[j], w2 * zkk[j]), akkb, acc);
+            zb[1 + j] = gpe_fma(wz + wz, akkb, s * akb);
+            acc = gpe_fma(wz, akb, acc);
+            acc = gpe_fma(gpe_fma(q * zk[j], zk[j], w2 * zkk[j]), akkb, acc);
         }
     } else {
         static_assert(E == 1, "second-order channels: one per axis, or the single Laplacian channel");
-        const float aLb = ab[1 + D];
+        const T aLb = ab[1 + D];
         zb[1 + D] = s * aLb;
-        const float g = (w2 + w2) * aLb;
-        float S = zk[0] * zk[0], dot = zk[0] * ab[1];
+        const T g = (w2 + w2) * aLb;
+        T S = zk[0] * zk[0], dot = zk[0] * ab[1];
 #pragma unroll
-        for (int j = 1; j < D; ++j) { S = fmaf(zk[j], zk[j], S); dot = fmaf(zk[j], ab[1 + j], dot); }
+        for (int j = 1; j < D; ++j) { S = gpe_fma(zk[j], zk[j], S); dot = gpe_fma(zk[j], ab[1 + j], dot); }
 #pragma unroll
-        for (int j = 0; j < D; ++j) zb[1 + j] = fmaf(g, zk[j], s * ab[1 + j]);
-        acc = fmaf(w2, dot, acc);
-        acc = fmaf(fmaf(q, S, w2 * zkk[0]), aLb, acc);
+        for (int j = 0; j < D; ++j) zb[1 + j] = gpe_fma(g, zk[j], s * ab[1 + j]);
+        acc = gpe_fma(w2, dot, acc);
+        acc = gpe_fma(gpe_fma(q, S, w2 * zkk[0]), aLb, acc);
     }
     zb[0] = acc;
 }

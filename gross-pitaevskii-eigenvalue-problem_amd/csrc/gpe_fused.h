@@ -120,17 +120,12 @@ __global__ __launch_bounds__(256, ((C <= 5 && H <= 64) ? GPE_FWD_WAVES : 1)) voi
         for (int nt = 0; nt < NT; ++nt) {
             f32x4 st[C];
             layer0_st<H, C, E>(w0s, xv, nt, q, st);
+            f32x4 a4[C];
+            act_from_stored<D, E>(st[0], st + 1, st + 1 + D, shift, a4);      // layer0_st leaves the second-order channels zero
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float zk[D > 0 ? D : 1], zkk[E > 0 ? E : 1], a[C];
+            for (int c = 0; c < C; ++c)
 #pragma unroll
-                for (int jd = 0; jd < D; ++jd) zk[jd] = st[1 + jd][r];
-#pragma unroll
-                for (int e = 0; e < E; ++e) zkk[e] = 0.f;
-                act_from_stored<D, E>(st[0][r], zk, zkk, shift, a);
-#pragma unroll
-                for (int c = 0; c < C; ++c) bufA[c][nt * 4 + r] = a[c];
-            }
+                for (int r = 0; r < 4; ++r) bufA[c][nt * 4 + r] = a4[c][r];
         }
         // ---- hidden -> hidden layer j on the matrix cores: a_in -> a_out -------------------------------------
         auto layer = [&](const float (&a_in)[C][NF], float (&a_out)[C][NF], int j) {
@@ -153,20 +148,13 @@ __global__ __launch_bounds__(256, ((C <= 5 && H <= 64) ? GPE_FWD_WAVES : 1)) voi
                         for (int c = 0; c < C; ++c)
                             acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[kt][s], a_in[c][kt * 4 + s], acc[c], 0, 0, 0);
 
-                f32x4 tt;
+                const f32x4 tt = gpe_tanh(acc[0]);
+                f32x4 a4[C];
+                act_from_stored<D, E>(tt, acc + 1, acc + 1 + D, shift, a4);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float t = gpe_tanh(acc[0][r]);
-                    tt[r] = t;
-                    float zk[D > 0 ? D : 1], zkk[E > 0 ? E : 1], a[C];
+                for (int c = 0; c < C; ++c)
 #pragma unroll
-                    for (int jd = 0; jd < D; ++jd) zk[jd] = acc[1 + jd][r];
-#pragma unroll
-                    for (int e = 0; e < E; ++e) zkk[e] = acc[1 + D + e][r];
-                    act_from_stored<D, E>(t, zk, zkk, shift, a);
-#pragma unroll
-                    for (int c = 0; c < C; ++c) a_out[c][nt * 4 + r] = a[c];
-                }
+                    for (int r = 0; r < 4; ++r) a_out[c][nt * 4 + r] = a4[c][r];
                 if (store_acts) {
                     float* sp = stored + ((((size_t)tile * (L - 1) + (j - 1)) * C) * NT + nt) * 256 + lane * 4;
                     *reinterpret_cast<f32x4*>(sp) = tt;
@@ -326,32 +314,28 @@ __global__ __launch_bounds__((NHH > 0 ? 256 : (WLDS ? 512 : 256)), ((NHH > 0 || 
                 f32x4 wo[NOUT];
 #pragma unroll
                 for (int o = 0; o < NOUT; ++o) wo[o] = *reinterpret_cast<const f32x4*>(&Wo[o * H + 16 * nt + 4 * q]);
+                f32x4 a4[C], ab4[C], zv4[C];
+                act_from_stored<D, E>(st[0], st + 1, st + 1 + D, shift, a4);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float zk[D > 0 ? D : 1], zkk[E > 0 ? E : 1], a[C], ab[C], zv[C];
+                for (int o = 0; o < NOUT; ++o) {
+                    f32x4 g = (f32x4)(0.f);
 #pragma unroll
-                    for (int jd = 0; jd < D; ++jd) zk[jd] = st[1 + jd][r];
+                    for (int c = 0; c < C; ++c) g = gpe_fma((f32x4)(ob[o][c]), a4[c], g);
 #pragma unroll
-                    for (int e = 0; e < E; ++e) zkk[e] = st[1 + D + e][r];
-                    act_from_stored<D, E>(st[0][r], zk, zkk, shift, a);
-#pragma unroll
-                    for (int o = 0; o < NOUT; ++o) {
-                        float g = 0.f;
-#pragma unroll
-                        for (int c = 0; c < C; ++c) g = fmaf(ob[o][c], a[c], g);
-                        gwo[o][nt * 4 + r] = g;
-                    }
-#pragma unroll
-                    for (int c = 0; c < C; ++c) {
-                        float v = 0.f;
-#pragma unroll
-                        for (int o = 0; o < NOUT; ++o) v = fmaf(wo[o][r], ob[o][c], v);
-                        ab[c] = v;
-                    }
-                    act_adjoint<D, E>(st[0][r], zk, zkk, ab, zv);
-#pragma unroll
-                    for (int c = 0; c < C; ++c) zb[c][nt * 4 + r] = zv[c];
+                    for (int r = 0; r < 4; ++r) gwo[o][nt * 4 + r] = g[r];
                 }
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    f32x4 v = (f32x4)(0.f);
+#pragma unroll
+                    for (int o = 0; o < NOUT; ++o) v = gpe_fma(wo[o], (f32x4)(ob[o][c]), v);
+                    ab4[c] = v;
+                }
+                act_adjoint<D, E>(st[0], st + 1, st + 1 + D, ab4, zv4);
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) zb[c][nt * 4 + r] = zv4[c][r];
             }
 #pragma unroll
             for (int o = 0; o < NOUT; ++o) row_reduce_add<NF>(gwo[o], &gacc[nd.offW[L] + o * H], 1, m, q);
@@ -430,19 +414,18 @@ __global__ __launch_bounds__((NHH > 0 ? 256 : (WLDS ? 512 : 256)), ((NHH > 0 || 
 #pragma unroll
                     for (int c = 0; c < C; ++c) st[c] = stn[c];
                     if (kt + 1 < NT) load_st(j - 1, kt + 1, stn);
+                    {
+                        f32x4 ab4[C], zv4[C];
+                        act_from_stored<D, E>(st[0], st + 1, st + 1 + D, shift, xa);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float zk[D > 0 ? D : 1], zkk[E > 0 ? E : 1], a[C], ab[C], zv[C];
+                        for (int c = 0; c < C; ++c)
 #pragma unroll
-                        for (int jd = 0; jd < D; ++jd) zk[jd] = st[1 + jd][r];
+                            for (int r = 0; r < 4; ++r) ab4[c][r] = zb[c][kt * 4 + r];
+                        act_adjoint<D, E>(st[0], st + 1, st + 1 + D, ab4, zv4);
 #pragma unroll
-                    for (int e = 0; e < E; ++e) zkk[e] = st[1 + D + e][r];
-                        act_from_stored<D, E>(st[0][r], zk, zkk, shift, a);
+                        for (int c = 0; c < C; ++c)
 #pragma unroll
-                        for (int c = 0; c < C; ++c) { xa[c][r] = a[c]; ab[c] = zb[c][kt * 4 + r]; }
-                        act_adjoint<D, E>(st[0][r], zk, zkk, ab, zv);
-#pragma unroll
-                        for (int c = 0; c < C; ++c) zb[c][kt * 4 + r] = zv[c];
+                            for (int r = 0; r < 4; ++r) zb[c][kt * 4 + r] = zv4[c][r];
                     }
                     STAMP(7);
                     tiles_transpose<C>(xa, xt, TT, m, q);
@@ -584,17 +567,7 @@ __global__ __launch_bounds__(H * 4, 2) void f_forward_coop(NetDesc nd, const flo
         {   // layer 0, own slice
             f32x4 st[C];
             layer0_st<H, C, E>(w0s, xv, w, q, st);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float zk[D > 0 ? D : 1], zkk[E > 0 ? E : 1], av[C];
-#pragma unroll
-                for (int jd = 0; jd < D; ++jd) zk[jd] = st[1 + jd][r];
-#pragma unroll
-                for (int e = 0; e < E; ++e) zkk[e] = 0.f;
-                act_from_stored<D, E>(st[0][r], zk, zkk, shift, av);
-#pragma unroll
-                for (int c = 0; c < C; ++c) a[c][r] = av[c];
-            }
+            act_from_stored<D, E>(st[0], st + 1, st + 1 + D, shift, a);          // layer0_st leaves the second-order channels zero
         }
 #pragma unroll
         for (int j = 1; j <= NHH; ++j) {
@@ -618,20 +591,8 @@ __global__ __launch_bounds__(H * 4, 2) void f_forward_coop(NetDesc nd, const flo
                         acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j - 1][kt][s2], bf[c][s2], acc[c], 0, 0, 0);
             }
 
-            f32x4 tt;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float t = gpe_tanh(acc[0][r]);
-                tt[r] = t;
-                float zk[D > 0 ? D : 1], zkk[E > 0 ? E : 1], av[C];
-#pragma unroll
-                for (int jd = 0; jd < D; ++jd) zk[jd] = acc[1 + jd][r];
-#pragma unroll
-                for (int e = 0; e < E; ++e) zkk[e] = acc[1 + D + e][r];
-                act_from_stored<D, E>(t, zk, zkk, shift, av);
-#pragma unroll
-                for (int c = 0; c < C; ++c) a[c][r] = av[c];
-            }
+            const f32x4 tt = gpe_tanh(acc[0]);
+            act_from_stored<D, E>(tt, acc + 1, acc + 1 + D, shift, a);
             if (store_acts) {
                 float* sp = stored + ((((size_t)tile * (L - 1) + (j - 1)) * C) * NT + w) * 256 + lane * 4;
                 *reinterpret_cast<f32x4*>(sp) = tt;
@@ -759,31 +720,25 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_coop(NetDesc nd, const fl
 #pragma unroll
             for (int o = 0; o < NOUT; ++o) wo[o] = *reinterpret_cast<const f32x4*>(&Wo[o * H + 16 * w + 4 * q]);
             float gwo[NOUT][4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float zk[D > 0 ? D : 1], zkk[E > 0 ? E : 1], a[C], ab[C], zv[C];
-#pragma unroll
-                for (int jd = 0; jd < D; ++jd) zk[jd] = st[1 + jd][r];
-#pragma unroll
-                for (int e = 0; e < E; ++e) zkk[e] = st[1 + D + e][r];
-                act_from_stored<D, E>(st[0][r], zk, zkk, shift, a);
+            {
+                f32x4 a4[C], ab4[C];
+                act_from_stored<D, E>(st[0], st + 1, st + 1 + D, shift, a4);
 #pragma unroll
                 for (int o = 0; o < NOUT; ++o) {
-                    float g = 0.f;
+                    f32x4 g = (f32x4)(0.f);
 #pragma unroll
-                    for (int c = 0; c < C; ++c) g = fmaf(ob[o][c], a[c], g);
-                    gwo[o][r] = g;
+                    for (int c = 0; c < C; ++c) g = gpe_fma((f32x4)(ob[o][c]), a4[c], g);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) gwo[o][r] = g[r];
                 }
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
-                    float v = 0.f;
+                    f32x4 v = (f32x4)(0.f);
 #pragma unroll
-                    for (int o = 0; o < NOUT; ++o) v = fmaf(wo[o][r], ob[o][c], v);
-                    ab[c] = v;
+                    for (int o = 0; o < NOUT; ++o) v = gpe_fma(wo[o], (f32x4)(ob[o][c]), v);
+                    ab4[c] = v;
                 }
-                act_adjoint<D, E>(st[0][r], zk, zkk, ab, zv);
-#pragma unroll
-                for (int c = 0; c < C; ++c) zb[c][r] = zv[c];
+                act_adjoint<D, E>(st[0], st + 1, st + 1 + D, ab4, zb);
             }
 #pragma unroll
             for (int o = 0; o < NOUT; ++o) row_reduce4_add(gwo[o], &gsm[(L - 1 + o) * H + 16 * w], m, q);
@@ -851,20 +806,8 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_coop(NetDesc nd, const fl
             if constexpr (!WREG) __builtin_amdgcn_sched_barrier(0);      // keep the phases' live ranges apart (256-register budget)
             // recompute X of layer j-1 (own slice), activation adjoint -> z of layer j-1, X^T into the shared buffer
             f32x4 xa[C];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float zk[D > 0 ? D : 1], zkk[E > 0 ? E : 1], a[C], ab[C], zv[C];
-#pragma unroll
-                for (int jd = 0; jd < D; ++jd) zk[jd] = st[1 + jd][r];
-#pragma unroll
-                for (int e = 0; e < E; ++e) zkk[e] = st[1 + D + e][r];
-                act_from_stored<D, E>(st[0][r], zk, zkk, shift, a);
-#pragma unroll
-                for (int c = 0; c < C; ++c) { xa[c][r] = a[c]; ab[c] = acc[c][r]; }
-                act_adjoint<D, E>(st[0][r], zk, zkk, ab, zv);
-#pragma unroll
-                for (int c = 0; c < C; ++c) zb[c][r] = zv[c];
-            }
+            act_from_stored<D, E>(st[0], st + 1, st + 1 + D, shift, xa);
+            act_adjoint<D, E>(st[0], st + 1, st + 1 + D, acc, zb);
 #pragma unroll
             for (int c = 0; c < C; ++c)
 #pragma unroll

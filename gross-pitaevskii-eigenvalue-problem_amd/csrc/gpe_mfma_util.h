@@ -3,7 +3,6 @@
 #pragma once
 #include "gpe_common.h"
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 
 #define F_PITCH 20   // floats per row of a transposition tile (16 + 4 pad; rows stay 16-B aligned)
@@ -114,16 +113,13 @@ GPE_DEV void layer0_st(const float* w0s, const float (&xv)[3], int nt, int q, f3
     const f32x4 w1 = *reinterpret_cast<const f32x4*>(&w0s[H + o]);
     const f32x4 w2 = *reinterpret_cast<const f32x4*>(&w0s[2 * H + o]);
     const f32x4 bb = *reinterpret_cast<const f32x4*>(&w0s[3 * H + o]);
+    const f32x4 z = gpe_fma(w2, (f32x4)(xv[2]), gpe_fma(w1, (f32x4)(xv[1]), gpe_fma(w0, (f32x4)(xv[0]), bb)));
+    st[0] = gpe_tanh(z);
+    if constexpr (D >= 1) st[1] = w0;
+    if constexpr (D >= 2) st[2] = w1;
+    if constexpr (D >= 3) st[3] = w2;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float z = fmaf(w2[r], xv[2], fmaf(w1[r], xv[1], fmaf(w0[r], xv[0], bb[r])));
-        st[0][r] = gpe_tanh(z);
-        if constexpr (D >= 1) st[1][r] = w0[r];
-        if constexpr (D >= 2) st[2][r] = w1[r];
-        if constexpr (D >= 3) st[3][r] = w2[r];
-#pragma unroll
-        for (int e = 0; e < E; ++e) st[1 + D + e][r] = 0.f;      // a linear map has no second derivatives
-    }
+    for (int e = 0; e < E; ++e) st[1 + D + e] = (f32x4)(0.f);        // a linear map has no second derivatives
 }
 
 GPE_DEV void row_reduce4_add(const float (&v)[4], float* dst16, int m, int q) {

@@ -91,17 +91,7 @@ __global__ __launch_bounds__(512, 2) void w_forward(NetDesc nd, const float* __r
         for (int rt = 0; rt < RT; ++rt) {                      // layer 0 (K = dim <= 3): VALU, own slice
             f32x4 st[C];
             layer0_st<H, C, E>(w0s, xv, w * RT + rt, q, st);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float zk[D > 0 ? D : 1], zkk[E > 0 ? E : 1], av[C];
-#pragma unroll
-                for (int jd = 0; jd < D; ++jd) zk[jd] = st[1 + jd][r];
-#pragma unroll
-                for (int e = 0; e < E; ++e) zkk[e] = 0.f;
-                act_from_stored<D, E>(st[0][r], zk, zkk, shift, av);
-#pragma unroll
-                for (int c = 0; c < C; ++c) a[rt][c][r] = av[c];
-            }
+            act_from_stored<D, E>(st[0], st + 1, st + 1 + D, shift, a[rt]);      // layer0_st leaves the second-order channels zero
         }
         for (int j = 1; j < L; ++j) {
             WSTAMP_ITER;
@@ -165,20 +155,8 @@ __global__ __launch_bounds__(512, 2) void w_forward(NetDesc nd, const float* __r
             WSTAMP(3);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                f32x4 tt;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float t = gpe_tanh(acc[rt][0][r]);
-                    tt[r] = t;
-                    float zk[D > 0 ? D : 1], zkk[E > 0 ? E : 1], av[C];
-#pragma unroll
-                    for (int jd = 0; jd < D; ++jd) zk[jd] = acc[rt][1 + jd][r];
-#pragma unroll
-                    for (int e = 0; e < E; ++e) zkk[e] = acc[rt][1 + D + e][r];
-                    act_from_stored<D, E>(t, zk, zkk, shift, av);
-#pragma unroll
-                    for (int c = 0; c < C; ++c) a[rt][c][r] = av[c];
-                }
+                const f32x4 tt = gpe_tanh(acc[rt][0]);
+                act_from_stored<D, E>(tt, acc[rt] + 1, acc[rt] + 1 + D, shift, a[rt]);
                 if (store_acts) {
                     float* sp = stored + ((((size_t)tile * (L - 1) + (j - 1)) * C) * NT + w * RT + rt) * 256 + lane * 4;
                     *reinterpret_cast<f32x4*>(sp) = tt;
@@ -280,31 +258,25 @@ __global__ __launch_bounds__(512, 2) void w_bwd_out(NetDesc nd, const float* __r
         for (int o = 0; o < NOUT; ++o) wo[o] = *reinterpret_cast<const f32x4*>(&Wo[o * H + 16 * ktile + 4 * q]);
         float gwo[NOUT][4];
         f32x4 zb[C];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float zk[D > 0 ? D : 1], zkk[E > 0 ? E : 1], a[C], ab[C], zv[C];
-#pragma unroll
-            for (int jd = 0; jd < D; ++jd) zk[jd] = st[1 + jd][r];
-#pragma unroll
-            for (int e = 0; e < E; ++e) zkk[e] = st[1 + D + e][r];
-            act_from_stored<D, E>(st[0][r], zk, zkk, shift, a);
+        {
+            f32x4 a4[C], ab4[C];
+            act_from_stored<D, E>(st[0], st + 1, st + 1 + D, shift, a4);
 #pragma unroll
             for (int o = 0; o < NOUT; ++o) {
-                float gg = 0.f;
+                f32x4 gg = (f32x4)(0.f);
 #pragma unroll
-                for (int c = 0; c < C; ++c) gg = fmaf(ob[o][c], a[c], gg);
-                gwo[o][r] = gg;
+                for (int c = 0; c < C; ++c) gg = gpe_fma((f32x4)(ob[o][c]), a4[c], gg);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gwo[o][r] = gg[r];
             }
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                float v = 0.f;
+                f32x4 v = (f32x4)(0.f);
 #pragma unroll
-                for (int o = 0; o < NOUT; ++o) v = fmaf(wo[o][r], ob[o][c], v);
-                ab[c] = v;
+                for (int o = 0; o < NOUT; ++o) v = gpe_fma(wo[o], (f32x4)(ob[o][c]), v);
+                ab4[c] = v;
             }
-            act_adjoint<D, E>(st[0][r], zk, zkk, ab, zv);
-#pragma unroll
-            for (int c = 0; c < C; ++c) zb[c][r] = zv[c];
+            act_adjoint<D, E>(st[0], st + 1, st + 1 + D, ab4, zb);
         }
 #pragma unroll
         for (int c = 0; c < C; ++c)
@@ -436,32 +408,27 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
 #pragma unroll
                 for (int o = 0; o < NO; ++o) wo[o] = *reinterpret_cast<const f32x4*>(&Wo[o * H + 16 * (w * RTZ + rt) + 4 * q]);
                 float gwo[NO][4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float zk[D > 0 ? D : 1], zkk[E > 0 ? E : 1], a[C], ab[C], zv[C];
-#pragma unroll
-                    for (int jd = 0; jd < D; ++jd) zk[jd] = zf[rt][1 + jd][r];
-#pragma unroll
-                    for (int e = 0; e < E; ++e) zkk[e] = zf[rt][1 + D + e][r];
-                    const float tt = zf[rt][0][r];
-                    act_from_stored<D, E>(tt, zk, zkk, shift, a);
+                {
+                    f32x4 a4[C], ab4[C], zv4[C];
+                    act_from_stored<D, E>(zf[rt][0], zf[rt] + 1, zf[rt] + 1 + D, shift, a4);
 #pragma unroll
                     for (int o = 0; o < NO; ++o) {
-                        float gg = 0.f;
+                        f32x4 gg = (f32x4)(0.f);
 #pragma unroll
-                        for (int c = 0; c < C; ++c) gg = fmaf(obv[o][c], a[c], gg);
-                        gwo[o][r] = gg;
+                        for (int c = 0; c < C; ++c) gg = gpe_fma((f32x4)(obv[o][c]), a4[c], gg);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) gwo[o][r] = gg[r];
                     }
 #pragma unroll
                     for (int c = 0; c < C; ++c) {
-                        float v = 0.f;
+                        f32x4 v = (f32x4)(0.f);
 #pragma unroll
-                        for (int o = 0; o < NO; ++o) v = fmaf(wo[o][r], obv[o][c], v);
-                        ab[c] = v;
+                        for (int o = 0; o < NO; ++o) v = gpe_fma(wo[o], (f32x4)(obv[o][c]), v);
+                        ab4[c] = v;
                     }
-                    act_adjoint<D, E>(tt, zk, zkk, ab, zv);
+                    act_adjoint<D, E>(zf[rt][0], zf[rt] + 1, zf[rt] + 1 + D, ab4, zv4);   // zf holds the stored (t, z_k, z_L) here
 #pragma unroll
-                    for (int c = 0; c < C; ++c) zf[rt][c][r] = zv[c];
+                    for (int c = 0; c < C; ++c) zf[rt][c] = zv4[c];
                 }
                 if (h == 0) {
 #pragma unroll
@@ -524,20 +491,8 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
         WSTAMP(4);
         // recompute X of layer j-1 (own tile), activation adjoint -> zbar_{j-1}
         f32x4 xa[C], zb[C];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float zk[D > 0 ? D : 1], zkk[E > 0 ? E : 1], a[C], ab[C], zv[C];
-#pragma unroll
-            for (int jd = 0; jd < D; ++jd) zk[jd] = st[1 + jd][r];
-#pragma unroll
-            for (int e = 0; e < E; ++e) zkk[e] = st[1 + D + e][r];
-            act_from_stored<D, E>(st[0][r], zk, zkk, shift, a);
-#pragma unroll
-            for (int c = 0; c < C; ++c) { xa[c][r] = a[c]; ab[c] = acc[c][r]; }
-            act_adjoint<D, E>(st[0][r], zk, zkk, ab, zv);
-#pragma unroll
-            for (int c = 0; c < C; ++c) zb[c][r] = zv[c];
-        }
+        act_from_stored<D, E>(st[0], st + 1, st + 1 + D, shift, xa);
+        act_adjoint<D, E>(st[0], st + 1, st + 1 + D, acc, zb);
         if constexpr (!FIRST) {
 #pragma unroll
             for (int c = 0; c < C; ++c)

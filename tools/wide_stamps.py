@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Per-phase cycle shares of the wide kernels (library built with -DGPE_STAMP; GPE_HIP_LIB points at it).
-usage: GPE_HIP_LIB=build/variants/libgpe_stamp.so python tools/wide_stamps.py"""
+usage: GPE_HIP_LIB=build/variants/libgpe_stamp.so python tools/wide_stamps.py [workload] [points]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import gpe_pinn, bench
-wl = bench.WORKLOADS["cfg5_3d_6x256"]
+wl = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "cfg5_3d_6x256"]
 x, dx, xb = bench.make_points(wl, 0, 1)
-x = x[:131072]
-cfg = gpe_pinn.GPEConfig(layers=wl["layers"], gamma=wl["gamma"], dx=dx, omega=wl["omega"], lr=1e-3)
+x = x[:int(sys.argv[2]) if len(sys.argv) > 2 else 131072]
+cfg = gpe_pinn.GPEConfig(layers=wl["layers"], gamma=wl["gamma"], dx=dx, omega=tuple(wl.get("omega", (1.0, 1.0, 1.0))), lr=1e-3)
 eng = gpe_pinn.Engine(cfg)
 eng.set_params(bench.reference_init(wl["layers"]))
 eng.bind_points(torch.as_tensor(x, device="cuda"))
