@@ -80,16 +80,20 @@ __global__ __launch_bounds__(256, ((C <= 5 && H <= 64) ? GPE_FWD_WAVES : 1)) voi
                                                                  int store_acts) {
     constexpr int D = C - 1 - E, NT = H / 16, NF = NT * 4;
     const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4;
+    const unsigned lane4 = (unsigned)lane * 4u;
     const int L = nd.n_lin - 1;
     const int dim = nd.dim;
     const int64_t ntiles = (N + 15) >> 4;
-    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    // wave index through readfirstlane: the tile number (and with it every stored-activation address) lives in SGPRs, the
+    // address arithmetic runs on the scalar unit instead of taking VALU cycles from the matrix products
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const float shift = nd.shift;
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
     float* w0s = lds_f;
     float* lds_w = lds_f + ((small_count(nd, H) + 3) & ~3);
     stage_layer0<H>(w0s, theta, nd, 256);
+    const buf_t rW = buf_make(Wpk, (unsigned)((L - 1) * H * H * 4));
     if constexpr (WLDS) {
         const int n4 = (L - 1) * H * H / 4;
         for (int i = threadIdx.x; i < n4; i += 256)
@@ -114,6 +118,8 @@ __global__ __launch_bounds__(256, ((C <= 5 && H <= 64) ? GPE_FWD_WAVES : 1)) voi
             for (int k = 0; k < 3; ++k) if (k < dim) xn[k] = pts_at(x, pn, dim, k);
         }
 
+        // this tile's block of stored activations: [L-1][C][NT][256] floats
+        const buf_t rS = buf_make(stored + (size_t)tile * (L - 1) * C * NT * 256, (unsigned)((L - 1) * C * NT * 1024));
         float bufA[C][NF], bufB[C][NF];
         // ---- layer 0 (K = dim <= 3): VALU -----------------------------------------------------------
 #pragma unroll
@@ -135,7 +141,10 @@ __global__ __launch_bounds__(256, ((C <= 5 && H <= 64) ? GPE_FWD_WAVES : 1)) voi
             for (int nt = 0; nt < NT; ++nt) {
                 f32x4 w[NT];
 #pragma unroll
-                for (int kt = 0; kt < NT; ++kt) w[kt] = *reinterpret_cast<const f32x4*>(&Wp[((nt * NT + kt) * 64 + lane) * 4]);
+                for (int kt = 0; kt < NT; ++kt) {
+                    if constexpr (WLDS) w[kt] = *reinterpret_cast<const f32x4*>(Wp + (nt * NT + kt) * 256 + lane4);
+                    else w[kt] = buf_load4(rW, lane4 * 4u, (unsigned)(((j - 1) * NT * NT + nt * NT + kt) * 1024));
+                }
                 f32x4 acc[C];
                 acc[0] = *reinterpret_cast<const f32x4*>(&bj[16 * nt + 4 * q]);
 #pragma unroll
@@ -155,11 +164,11 @@ __global__ __launch_bounds__(256, ((C <= 5 && H <= 64) ? GPE_FWD_WAVES : 1)) voi
                 for (int c = 0; c < C; ++c)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) a_out[c][nt * 4 + r] = a4[c][r];
-                if (store_acts) {
-                    float* sp = stored + ((((size_t)tile * (L - 1) + (j - 1)) * C) * NT + nt) * 256 + lane * 4;
-                    *reinterpret_cast<f32x4*>(sp) = tt;
+                if (store_acts) {                                    // uniform base (SGPRs) + 32-bit lane offset
+                    const unsigned so = (unsigned)(((j - 1) * C * NT + nt) * 1024);
+                    buf_store4(tt, rS, lane4 * 4u, so);
 #pragma unroll
-                    for (int c = 1; c < C; ++c) *reinterpret_cast<f32x4*>(sp + (size_t)c * NT * 256) = acc[c];
+                    for (int c = 1; c < C; ++c) buf_store4(acc[c], rS, lane4 * 4u, so + (unsigned)(c * NT * 1024));
                 }
             }
         };

@@ -5,6 +5,21 @@
 
 
 
+// Buffer addressing: descriptor (base, size) in SGPRs + one 32-bit per-lane byte offset + a wave-uniform byte offset that the
+// scalar unit computes.  With plain pointers hipcc forms 64-bit per-lane addresses with VALU adds -- and on gfx950 every VALU
+// cycle is a cycle the fp32 MFMAs do not get.  Out-of-range accesses are dropped by the hardware: sizes must be exact.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t buf_t;
+GPE_DEV buf_t buf_make(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+GPE_DEV f32x4 buf_load4(buf_t r, unsigned lane_bytes, unsigned uni_bytes) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_bytes, uni_bytes, 0));
+}
+GPE_DEV void buf_store4(f32x4 v, buf_t r, unsigned lane_bytes, unsigned uni_bytes) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, lane_bytes, uni_bytes, 0);
+}
+
 #define F_PITCH 20   // floats per row of a transposition tile (16 + 4 pad; rows stay 16-B aligned)
 
 GPE_DEV void wave_lds_fence() {

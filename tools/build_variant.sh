@@ -1,11 +1,16 @@
 #!/bin/bash
-# usage: tools/build_variant.sh <name> [extra hipcc flags]  ->  build/variants/libgpe_<name>.so
-# Kernel-tuning builds: -DGPE_FAST_BUILD compiles only the H = 64, n_out = 1, C in {1, 5} kernels (the NS workload), ~20 s.
+# usage: tools/build_variant.sh <name> [extra hipcc flags]  ->  build/variants/libgpe_<name>.so (+ build/variants/<name>_engine.o)
+# Kernel-tuning builds: -DGPE_FAST_BUILD compiles only the H = 64, n_out = 1, C in {1, 4, 5} kernels (the NS workload) and the
+# 3D H = 256 wide kernels, ~40 s.
 set -e
 root=$(cd "$(dirname "$0")/.." && pwd)
 name=$1; shift
 mkdir -p $root/build/variants
 cd $root/gross-pitaevskii-eigenvalue-problem_amd/csrc
-/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -shared -fPIC -DGPE_FAST_BUILD "$@" -I ../../include \
-    -o $root/build/variants/libgpe_$name.so gpe_engine.hip 2>&1 | grep -E "error|ScratchSize" || true
+for u in gpe_engine gpe_wide; do
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -DGPE_FAST_BUILD "$@" -I ../../include -c $u.hip \
+      -o $root/build/variants/${name}_$u.o 2>&1 | grep -E "error|ScratchSize" || true
+done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $root/build/variants/libgpe_$name.so \
+    $root/build/variants/${name}_gpe_engine.o $root/build/variants/${name}_gpe_wide.o
 ls -la $root/build/variants/libgpe_$name.so
