@@ -664,7 +664,7 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_coop(NetDesc nd, const fl
     float* w0s = g0 + 4 * H;
     float* ZB = w0s + ((small_count(nd, H) + 3) & ~3);
     float* XT = ZB + C * NT * 256;
-    const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* TT = XT + C * NT * F_TILE + w * (C * F_TILE);
     const int dim = nd.dim;
     const float shift = nd.shift;
@@ -711,11 +711,12 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_coop(NetDesc nd, const fl
 #pragma unroll
             for (int c = 0; c < C; ++c) ob[o][c] = valid ? Ob[((int64_t)c * NOUT + o) * ld + pm] : 0.f;
         // stored (t, z_k, z_L) of hidden layer h, this wave's feature slice
+        // (buffer addressing: the tile's block [L-1][C][NT][256] behind one descriptor, offsets on the scalar unit)
+        const buf_t rS = buf_make(stored + (size_t)tile * (L - 1) * C * NT * 256, (unsigned)((L - 1) * C * NT * 1024));
         auto load_st = [&](int h, f32x4 (&st)[C]) {
             if (h >= 1) {
-                const float* sp = stored + ((((size_t)tile * (L - 1) + (h - 1)) * C) * NT + w) * 256 + lane * 4;
 #pragma unroll
-                for (int c = 0; c < C; ++c) st[c] = *reinterpret_cast<const f32x4*>(sp + (size_t)c * NT * 256);
+                for (int c = 0; c < C; ++c) st[c] = buf_load4(rS, (unsigned)lane * 16u, (unsigned)((((h - 1) * C + c) * NT + w) * 1024));
             } else {
                 layer0_st<H, C, E>(w0s, xv, w, q, st);
             }
