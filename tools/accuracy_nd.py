@@ -99,7 +99,10 @@ for si, g in enumerate(gam):
         eng.run(ne)
     else:                                   # last stage: tighter normalisation, learning rate stepped down (Adam state kept)
         eng.set_loss_weights(1.0, a.w_bc, a.w_norm_final, 0.0, 0.0, a.w_riesz)
-        for frac, lr in ((0.35, a.lr), (0.2, a.lr * 0.3), (0.2, a.lr * 0.1), (0.15, a.lr * 0.03), (0.1, a.lr * 0.01)):
+        # (the ladder ends at lr x 1e-3: Adam turns gradient round-off into steps of size lr, and mu follows the norm with
+        #  d mu / d int ~ 8 -- at lr 1e-5 the norm integral wanders by ~2e-4, i.e. mu by ~1.5e-3 for some seeds)
+        for frac, lr in ((0.35, a.lr), (0.2, a.lr * 0.3), (0.15, a.lr * 0.1), (0.1, a.lr * 0.03), (0.1, a.lr * 0.01), (0.05, a.lr * 0.003),
+                         (0.05, a.lr * 0.001)):
             eng.set_lr(lr)
             left = int(ne * frac)
             while left > 0:                       # progress line at least every ~10 000 epochs (a silent GPU job is taken to be hung)
@@ -114,6 +117,15 @@ for si, g in enumerate(gam):
           f"({time.time() - t0:.0f} s)", flush=True)
 wall = time.time() - t0
 mu = rows[-1]["mu"]
+# mu of the NORMALISED state u / sqrt(int), from the three scalars of the last stage: with A = (kinetic + potential) / int and
+# B = g int(u^4) / int, the Rayleigh quotient is A + B and the variational energy of the normalised state A + B / (2 int); the
+# chemical potential of the normalised state is A + B / int.  (d mu / d int = B ~ 8 here: a norm that is off by 1e-4 moves the
+# raw quotient by 1e-3 although the state itself -- energy, density -- is right.)
+_int, _E = rows[-1]["norm"], rows[-1]["riesz"]
+mu_normalised = None
+if a.w_riesz != 0.0 and _int > 0.5:
+    _B = (mu - _E) / (1.0 - 0.5 / _int)
+    mu_normalised = (mu - _B) + _B / _int
 # ---- density on a test grid vs the solver ----
 from oracle import gp_ground_state_nd as nd
 gr = truth["grids"][0]
@@ -130,13 +142,16 @@ dref = dref / (dref.sum() * ht)
 out = dict(case=a.case, workload=cs["workload"], layers=cs["layers"], points=int(X.shape[0]), grid_per_axis=n, stages=rows,
            total_epochs=int(sum(r["epochs"] for r in rows)) + a.pretrain, wall_seconds=wall,
            mu=mu, mu_ref=mu_ref, mu_abs_err=abs(mu - mu_ref), mu_ref_source="oracle/gp_ground_truth.json:" + cs["truth"],
+           mu_normalised_state=mu_normalised, mu_normalised_state_abs_err=(abs(mu_normalised - mu_ref) if mu_normalised is not None else None),
+           norm_integral=_int, seed=a.seed,
            density_max_abs_err=float(np.abs(dens - dref).max()), density_max=float(dref.max()),
            density_rel_l2=float(np.sqrt(((dens - dref) ** 2).sum() / (dref ** 2).sum())),
            schedule=dict(pretrain=a.pretrain, epochs=a.epochs, final=a.final, stages=a.stages, lr=a.lr, w_norm=a.w_norm, w_bc=a.w_bc,
                          w_riesz=a.w_riesz, w_norm_final=a.w_norm_final,
-                         scheduler="constant lr per stage, fresh Adam per stage; last stage lr x (1, 0.3, 0.1, 0.03, 0.01)"),
+                         scheduler="constant lr per stage, fresh Adam per stage; last stage lr x (1, 0.3, 0.1, 0.03, 0.01, 0.003, 0.001)"),
            energy=rows[-1]["riesz"], energy_ref=truth["energy"])
 path = a.out or os.path.join(ROOT, "gpurun_out", f"accuracy_{cs['workload']}.json")
 os.makedirs(os.path.dirname(path), exist_ok=True)
 json.dump(out, open(path, "w"), indent=1)
-print(f"mu {mu:.6f}  mu_ref {mu_ref:.6f}  |err| {abs(mu - mu_ref):.2e}   density rel L2 {out['density_rel_l2']:.2e}   {wall:.0f} s")
+print(f"mu {mu:.6f}  mu_ref {mu_ref:.6f}  |err| {abs(mu - mu_ref):.2e}   normalised state: mu {mu_normalised if mu_normalised is not None else float('nan'):.6f} "
+      f"|err| {abs(mu_normalised - mu_ref) if mu_normalised is not None else float('nan'):.2e} (int {_int:.6f})   density rel L2 {out['density_rel_l2']:.2e}   {wall:.0f} s")
