@@ -237,6 +237,7 @@ struct gpe_engine {
     bool acc_clean = false;                       // step sums are zero (left so by k_update): the next step needs no k_begin
     bool ext_exchange = false;
     bool fwd_wlds = false;                        // forward kernel stages the hidden-hidden weights in LDS
+    bool fwd_b6 = false;                          // f_forward_b6: H x H maps as six bf16 MFMA products per fp32 product (H <= 64; GPE_FWD_B6)
     bool bwd_racc = false;                        // reverse kernel keeps the H x H weight gradients in registers (1 wave/SIMD)
     int nslab_g = 16;                             // H = 128: number of global-atomic gradient slabs
     int coop = 1;                                 // cooperative reverse kernel: 0 never, 1 whenever compiled for the shape, -1 by batch size
@@ -455,6 +456,29 @@ static void launch_f_forward(gpe_engine* e, Batch& b, unsigned grid, int store) 
     if constexpr (HH > 64) {
         F_LAUNCH(f_forward, HH, CC, EE, false, grid, 256, fused_fwd_lds(e, false), e->nd, e->theta, e->Wpk, b.pts, b.stored, b.O, b.n, b.ld, store);
         return;
+    }
+    if constexpr (HH <= 64) {
+        if (e->fwd_b6 && staged_batch(e, b)) {
+            // weights (three bf16 pieces, 6 bytes each) in LDS when two workgroups per CU still fit
+            const size_t w6 = (size_t)(e->nd.n_lin - 2) * HH * HH * 6;
+            const bool wl = 2 * (fused_small_bytes(e) + w6) <= (size_t)160 * 1024;
+            const size_t lds6 = fused_small_bytes(e) + (wl ? w6 : 0);
+#define B6ARGS e->nd, e->theta, e->WpkT, b.pts, b.stored, b.O, b.n, b.ld, store
+#ifdef GPE_FAST_BUILD
+            if (wl) hipLaunchKernelGGL((f_forward_b6<HH, CC, EE, 1, true>), dim3(grid), dim3(256), lds6, e->stream, B6ARGS);
+            else hipLaunchKernelGGL((f_forward_b6<HH, CC, EE, 1, false>), dim3(grid), dim3(256), lds6, e->stream, B6ARGS);
+#else
+            if (e->nd.n_out == 1) {
+                if (wl) hipLaunchKernelGGL((f_forward_b6<HH, CC, EE, 1, true>), dim3(grid), dim3(256), lds6, e->stream, B6ARGS);
+                else hipLaunchKernelGGL((f_forward_b6<HH, CC, EE, 1, false>), dim3(grid), dim3(256), lds6, e->stream, B6ARGS);
+            } else {
+                if (wl) hipLaunchKernelGGL((f_forward_b6<HH, CC, EE, 2, true>), dim3(grid), dim3(256), lds6, e->stream, B6ARGS);
+                else hipLaunchKernelGGL((f_forward_b6<HH, CC, EE, 2, false>), dim3(grid), dim3(256), lds6, e->stream, B6ARGS);
+            }
+#endif
+#undef B6ARGS
+            return;
+        }
     }
     if (e->fwd_wlds && staged_batch(e, b))
         F_LAUNCH(f_forward, HH, CC, EE, true, grid, 256, fused_fwd_lds(e, true), e->nd, e->theta, e->Wpk, b.pts, b.stored, b.O, b.n, b.ld, store);
@@ -898,6 +922,7 @@ int gpe_active_kernels(gpe_engine* e, char* buf, size_t n) {
     } else if (e->path == GPE_PATH_FUSED) {
         const bool fc = fwd_coop(e, b) && (e->H <= 64 || b.C <= 4);
         if (fc) snprintf(f, sizeof f, "f_forward_coop<%d,%d,%d,%d,%d>", e->H, b.C, b.E, e->nd.n_out, maps > 5 ? 5 : maps);
+        else if (e->H <= 64 && e->fwd_b6 && staged_batch(e, b)) snprintf(f, sizeof f, "f_forward_b6<%d,%d,%d,%d>", e->H, b.C, b.E, e->nd.n_out);
         else snprintf(f, sizeof f, "f_forward<%d,%d,%d,%d,%s>", e->H, b.C, b.E, e->nd.n_out,
                       (e->H <= 64 && e->fwd_wlds && staged_batch(e, b)) ? "wlds" : "l2");
         const int kind = bwd_kind(e, b);
@@ -1012,7 +1037,8 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
     if (ok && e->path == GPE_PATH_FUSED) {
         e->nslab = (H >= 128) ? std::max(e->nslab_g, e->num_cu) : e->num_cu * 2;     // H = 128: 16 atomic slabs, or one per workgroup (cooperative)
         if (e->wide) wide_init();
-        ok = alloc((void**)&e->Wpk, (size_t)(Lh - 1) * H * H * 4) && alloc((void**)&e->WpkT, (size_t)(Lh - 1) * H * H * 4) &&
+        // WpkT is followed by the bf16 pieces of the same maps (3 x 2 bytes per weight; pack_weight_element, f_forward_b6)
+        ok = alloc((void**)&e->Wpk, (size_t)(Lh - 1) * H * H * 4) && alloc((void**)&e->WpkT, (size_t)(Lh - 1) * H * H * (4 + 6)) &&
              alloc((void**)&e->gslab, (size_t)e->nslab * e->Ppad * 4);
         if (ok) {
             const int Cmain = dim + 2;        // training batches: value, dim first derivatives, Laplacian
@@ -1021,6 +1047,8 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
             const bool want = env ? (atoi(env) != 0) : true;
             const size_t smallb = ((size_t)(4 + (Lh - 1) + no) * H + 8) * sizeof(float);
             e->fwd_wlds = want && H <= 64 && wb + smallb <= 64 * 1024;
+            const char* envb6 = getenv("GPE_FWD_B6");                  // 1: f_forward_b6 for the large-batch forward pass at H <= 64
+            e->fwd_b6 = envb6 && atoi(envb6) != 0 && H <= 64;
             const char* envc = getenv("GPE_COOP");
             e->coop = envc ? atoi(envc) : 1;          // measured: faster than the per-wave-tile kernels at every batch size
             const char* envm = getenv("GPE_COOP_MAX_TILES");
@@ -1046,7 +1074,8 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
     (void)hipFuncSetAttribute((const void*)f_backward_coop<HH, CC, EE, NO, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
     (void)hipFuncSetAttribute((const void*)f_backward_coop<HH, CC, EE, NO, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
     (void)hipFuncSetAttribute((const void*)f_backward_coop<HH, CC, EE, NO, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
-    (void)hipFuncSetAttribute((const void*)f_forward<HH, CC, EE, NO, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_f)
+    (void)hipFuncSetAttribute((const void*)f_forward<HH, CC, EE, NO, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_f);      \
+    (void)hipFuncSetAttribute((const void*)f_forward_b6<HH, CC, EE, NO, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)
 #ifdef GPE_FAST_BUILD
             SETLDS(64, 1, 0, 1); SETLDS(64, 4, 1, 1);
 #else

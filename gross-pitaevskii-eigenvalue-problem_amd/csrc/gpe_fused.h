@@ -41,6 +41,14 @@
 // pack hidden-hidden weights (linear maps 1..L-1) in MFMA fragment order.
 //   Wpk [j-1][nt][kt][lane][s] = W_j[16nt + (lane&15)][16kt + 4(lane>>4) + s]      (forward A operand)
 //   WpkT[j-1][kt][nt][lane][s] = W_j[16nt + 4(lane>>4) + s][16kt + (lane&15)]      (backward A operand)
+// x = hi + mid + lo + O(2^-24 |x|), every piece exactly representable in bf16 (truncation: the remainders are exact in fp32)
+GPE_DEV float bf16_trunc(float x) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xffff0000u); }
+GPE_DEV void bf16_split3(float x, float& hi, float& mid, float& lo) {
+    hi = bf16_trunc(x);
+    const float r1 = x - hi;
+    mid = bf16_trunc(r1);
+    lo = r1 - mid;                                                  // (its low 16 bits are dropped when it is packed)
+}
 GPE_DEV void pack_weight_element(const NetDesc& nd, int H, const float* __restrict__ theta, float* __restrict__ Wpk,
                                  float* __restrict__ WpkT, int idx) {
     const int NT = H / 16;
@@ -52,6 +60,20 @@ GPE_DEV void pack_weight_element(const NetDesc& nd, int H, const float* __restri
     const float* W = theta + nd.offW[j];
     Wpk[idx] = W[(16 * a + i) * H + 16 * b + 4 * q + s];           // a = nt, b = kt
     WpkT[idx] = W[(16 * b + 4 * q + s) * H + 16 * a + i];          // a = kt, b = nt
+    // bf16 pieces for f_forward_b6 (behind WpkT in the same allocation):
+    //   W6[j-1][piece][nt][kb][lane][e] = piece of W_j[16nt + (lane&15)][32kb + 16(e>>2) + 4(lane>>4) + (e&3)],  W = hi + mid + lo
+    {
+        unsigned short* W6 = reinterpret_cast<unsigned short*>(WpkT + (size_t)(nd.n_lin - 2) * per);
+        const int e8 = e & 7, ln = (e >> 3) & 63, t3 = e >> 9;     // t3 = nt * (NT/2) + kb
+        const int nt = t3 / (NT / 2), kb = t3 % (NT / 2);
+        const float wv = W[(16 * nt + (ln & 15)) * H + 32 * kb + 16 * (e8 >> 2) + 4 * (ln >> 4) + (e8 & 3)];
+        float ph, pm, pl;
+        bf16_split3(wv, ph, pm, pl);
+        const size_t o = ((size_t)(j - 1) * 3 * per) + (size_t)e;  // piece stride = per
+        W6[o] = (unsigned short)(__builtin_bit_cast(unsigned, ph) >> 16);
+        W6[o + per] = (unsigned short)(__builtin_bit_cast(unsigned, pm) >> 16);
+        W6[o + 2 * (size_t)per] = (unsigned short)(__builtin_bit_cast(unsigned, pl) >> 16);
+    }
 }
 __global__ void k_pack_weights(NetDesc nd, int H, const float* __restrict__ theta, float* __restrict__ Wpk,
                                float* __restrict__ WpkT) {
@@ -203,6 +225,157 @@ __global__ __launch_bounds__(256, ((C <= 5 && H <= 64) ? GPE_FWD_WAVES : 1)) voi
         for (; j + 1 < L; j += 2) { layer(bufA, bufB, j); layer(bufB, bufA, j + 1); }   // ping-pong: no register copies
         if (j < L) { layer(bufA, bufB, j); output(bufB); }
         else output(bufA);
+    }
+}
+
+// f_forward with the H x H maps on the bf16 matrix instruction at fp32 accuracy: each fp32 operand is three bf16 pieces
+// (hi + mid + lo, 24 significant bits) and a product is the six piece products hh, hm, mh, hl, lh, mm accumulated in fp32 -- the dropped
+// ones are O(2^-24).  v_mfma_f32_16x16x32_bf16 covers K = 32 in 16 cycles, so six of them cost 96 cycles where eight
+// v_mfma_f32_16x16x4_f32 cost 256 (tools/ubench/mfma_bf16_split.hip: 2.6x, max error 1.4e-6 against 2.1e-6 of the fp32 instruction at
+// K = 64).  K slot 8 kq + e of block kb is feature 32 kb + 16 (e >> 2) + 4 kq + (e & 3): a lane's B operand is eight values it
+// already holds (two output fragments of the previous layer), so the layers still chain without data movement; the weights are
+// packed to match (pack_weight_element).  Price: ~5 VALU instructions per activation value for the split.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+GPE_DEV unsigned bf16_pack2(float lo_elem, float hi_elem) {         // bf16(lo_elem) | bf16(hi_elem) << 16, by truncation
+    return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, hi_elem), __builtin_bit_cast(unsigned, lo_elem), 0x07060302u);
+}
+template <int H, int C, int E, int NOUT, bool WLDS>
+__global__ __launch_bounds__(256, 2) void f_forward_b6(NetDesc nd, const float* __restrict__ theta, const float* __restrict__ WpkT,
+                                                        Pts x, float* __restrict__ stored, float* __restrict__ O, int64_t N,
+                                                        int64_t ld, int store_acts) {
+    constexpr int D = C - 1 - E, NT = H / 16, NF = NT * 4, KB = NT / 2;
+    static_assert(NT % 2 == 0, "K blocks of 32 features");
+    const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4;
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const int L = nd.n_lin - 1;
+    const int dim = nd.dim;
+    const int64_t ntiles = (N + 15) >> 4;
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const float shift = nd.shift;
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    float* w0s = lds_f;
+    stage_layer0<H>(w0s, theta, nd, 256);
+    // the piece arrays: [map][piece][nt][kb][lane] x 16 B; WLDS: staged once per workgroup (72 KB for three 64 x 64 maps)
+    const float* W6 = WpkT + (size_t)(L - 1) * H * H;
+    const buf_t rW = buf_make(W6, (unsigned)((L - 1) * 3 * H * H * 2));
+    const u32x4* lds_w = reinterpret_cast<const u32x4*>(lds_f + ((small_count(nd, H) + 3) & ~3));
+    if constexpr (WLDS) {
+        u32x4* dst = reinterpret_cast<u32x4*>(lds_f + ((small_count(nd, H) + 3) & ~3));
+        const int n16 = (L - 1) * 3 * H * H * 2 / 16;
+        for (int i = threadIdx.x; i < n16; i += 256) dst[i] = reinterpret_cast<const u32x4*>(W6)[i];
+    }
+    __syncthreads();
+
+    float xn[3] = {0.f, 0.f, 0.f};
+    if (wave0 < ntiles) {
+        const int64_t p0 = min(wave0 * 16 + m, N - 1);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) if (k < dim) xn[k] = pts_at(x, p0, dim, k);
+    }
+    for (int64_t tile = wave0; tile < ntiles; tile += nwaves) {
+        const int64_t pm = tile * 16 + m;
+        const bool valid = pm < N;
+        float xv[3] = {xn[0], xn[1], xn[2]};
+        if (tile + nwaves < ntiles) {
+            const int64_t pn = min((tile + nwaves) * 16 + m, N - 1);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) if (k < dim) xn[k] = pts_at(x, pn, dim, k);
+        }
+        const buf_t rS = buf_make(stored + (size_t)tile * (L - 1) * C * NT * 256, (unsigned)((L - 1) * C * NT * 1024));
+        float act[C][NF];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {                           // layer 0 (K = dim <= 3): VALU
+            f32x4 st[C];
+            layer0_st<H, C, E>(w0s, xv, nt, q, st);
+            f32x4 a4[C];
+            act_from_stored<D, E>(st[0], st + 1, st + 1 + D, shift, a4);
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) act[c][nt * 4 + r] = a4[c][r];
+        }
+        for (int j = 1; j < L; ++j) {
+            // ---- split the layer input: B operand pieces, eight k slots per lane and K block --------------------------------
+            u32x4 bp[C][KB][3];
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                    for (int pr = 0; pr < 4; ++pr) {                // pair pr = slots 2pr, 2pr+1 = registers (2kb + (pr>>1))*4 + 2(pr&1), +1
+                        const float x0 = act[c][(2 * kb + (pr >> 1)) * 4 + 2 * (pr & 1)], x1 = act[c][(2 * kb + (pr >> 1)) * 4 + 2 * (pr & 1) + 1];
+                        float h0, m0, l0, h1, m1, l1;
+                        bf16_split3(x0, h0, m0, l0);
+                        bf16_split3(x1, h1, m1, l1);
+                        bp[c][kb][0][pr] = bf16_pack2(x0, x1);      // (the top halves of x and of its hi piece are the same bits)
+                        bp[c][kb][1][pr] = bf16_pack2(m0, m1);
+                        bp[c][kb][2][pr] = bf16_pack2(l0, l1);
+                    }
+            const float* bj = w0s + (4 + (j - 1)) * H;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                u32x4 wp[KB][3];
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc)
+                        wp[kb][pc] = WLDS ? lds_w[((((j - 1) * 3 + pc) * NT + nt) * KB + kb) * 64 + lane]
+                                          : __builtin_bit_cast(u32x4, buf_load4(rW, lane16, (unsigned)(((((j - 1) * 3 + pc) * NT + nt) * KB + kb) * 1024)));
+                f32x4 acc[C];
+                acc[0] = *reinterpret_cast<const f32x4*>(&bj[16 * nt + 4 * q]);
+#pragma unroll
+                for (int c = 1; c < C; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                // smallest products first; C independent accumulator chains
+                constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                        for (int c = 0; c < C; ++c)
+                            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wp[kb][PA[t]]),
+                                                                             __builtin_bit_cast(bf16x8, bp[c][kb][PB[t]]), acc[c], 0, 0, 0);
+                const f32x4 tt = gpe_tanh(acc[0]);
+                f32x4 a4[C];
+                act_from_stored<D, E>(tt, acc + 1, acc + 1 + D, shift, a4);
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) act[c][nt * 4 + r] = a4[c][r];     // (the pieces of the old values are already in bp)
+                if (store_acts) {
+                    const unsigned so = (unsigned)(((j - 1) * C * NT + nt) * 1024);
+                    buf_store4(tt, rS, lane16, so);
+#pragma unroll
+                    for (int c = 1; c < C; ++c) buf_store4(acc[c], rS, lane16, so + (unsigned)(c * NT * 1024));
+                }
+            }
+        }
+        // ---- output layer (n_out <= 2): VALU dot + reduction over the 4 q-lanes of a point ------------------
+        const float* Wo = w0s + (4 + L - 1) * H;
+        const float* bo = w0s + (4 + L - 1 + NOUT) * H;
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+            float part[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) part[c] = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(&Wo[o * H + 16 * nt + 4 * q]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < C; ++c) part[c] = fmaf(wv[r], act[c][nt * 4 + r], part[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                float v = part[c];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                if (c == 0) v += bo[o];
+                if (q == 0 && valid) O[((int64_t)c * NOUT + o) * ld + pm] = v;
+            }
+        }
     }
 }
 

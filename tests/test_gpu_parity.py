@@ -874,3 +874,32 @@ def test_wide_set_output_layer_fused_or_separate_agree():
             os.environ.pop("GPE_WIDE_TOP", None) if old is None else os.environ.__setitem__("GPE_WIDE_TOP", old)
     assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[0][0])
     assert H.rel_err(res[0][1], res[1][1]) < 3e-6
+
+
+@pytest.mark.parametrize("name", ["2d_64x4_g500", "1d_64x3_refine", "1d_32x4_nb_sym", "3d_64x3_aniso", "2d_64x3_complex_rot", "2d_N17_ragged"])
+def test_forward_b6_matches_oracle(name):
+    """GPE_FWD_B6=1 (opt-in): the H x H maps of the large-batch forward kernel as six bf16 matrix products per fp32 product (three bf16
+    pieces per operand, fp32 accumulation; f_forward_b6).  Same tolerances as the fp32-MFMA kernel: the split keeps 24 significant bits."""
+    import os
+    kw, N, _ = CASES[name]
+    x, flat, x_bc = _inputs(kw, N, scale=_scale(kw))
+    pb = go.Problem(**kw)
+    osc, ograd, ores = go.full_loss_and_grad(pb, flat.astype(np.float64), x.astype(np.float64), x_bc.astype(np.float64))
+    old = {k: os.environ.get(k) for k in ("GPE_FWD_B6", "GPE_COOP_FWD_MAX_TILES")}
+    os.environ["GPE_FWD_B6"] = "1"
+    os.environ["GPE_COOP_FWD_MAX_TILES"] = "0"          # small batches would take the cooperative forward kernel
+    try:
+        eng = make_engine(pb, flat, x, x_bc, path=gpe_pinn.PATH_FUSED)
+        assert eng.active_kernels["fwd"].startswith("f_forward_b6<")
+        rs, psi, res = eng.residual()
+        assert close(psi.cpu().numpy(), ores["psi"], 5e-6, 2e-6)
+        assert close(res.cpu().numpy(), ores["residual"], 2e-5, 1e-5)
+        sc = eng.step()
+        f = 10.0 if N < 4 else 1.0
+        for k, tol in (("mu", 2e-5), ("loss", 1e-4), ("pde", 1e-4), ("norm", 2e-4)):
+            assert abs(sc[k] - osc[k]) <= f * tol * max(abs(osc[k]), 1e-6), (k, sc[k], osc[k])
+        assert H.rel_err(eng.get_grad(), ograd) < f * 5e-5
+        eng.close()
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
