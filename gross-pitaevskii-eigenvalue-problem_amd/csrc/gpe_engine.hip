@@ -238,6 +238,7 @@ struct gpe_engine {
     bool ext_exchange = false;
     bool fwd_wlds = false;                        // forward kernel stages the hidden-hidden weights in LDS
     bool fwd_b6 = false;                          // f_forward_b6: H x H maps as six bf16 MFMA products per fp32 product (H <= 64; GPE_FWD_B6)
+    bool bwd_b6 = false;                          // f_backward_coop<..., B6>: the adjoint products the same way (H <= 64; GPE_BWD_B6)
     bool bwd_racc = false;                        // reverse kernel keeps the H x H weight gradients in registers (1 wave/SIMD)
     int nslab_g = 16;                             // H = 128: number of global-atomic gradient slabs
     int coop = 1;                                 // cooperative reverse kernel: 0 never, 1 whenever compiled for the shape, -1 by batch size
@@ -502,12 +503,22 @@ static int bwd_kind(gpe_engine* e, const Batch& b) {
 static size_t coop_lds(gpe_engine* e, int C) {
     const int H = e->H, NT = H / 16, L = e->nd.n_lin - 1;
     const size_t n_gsm = ((size_t)(L - 1 + e->nd.n_out) * H + 4 + 3) & ~(size_t)3;
-    return (n_gsm + 4 * (size_t)H) * sizeof(float) + fused_small_bytes(e) +
-           ((size_t)C * NT * 256 + 2 * (size_t)C * NT * F_TILE) * sizeof(float);
+    const size_t zb = e->bwd_b6 && H <= 64 ? (size_t)3 * C * (NT / 2) * 256 : (size_t)C * NT * 256;     // B6: three bf16 pieces, 24 B per four values
+    return (n_gsm + 4 * (size_t)H) * sizeof(float) + fused_small_bytes(e) + (zb + 2 * (size_t)C * NT * F_TILE) * sizeof(float);
 }
 template <int HH, int CC, int EE, int NO>
 static void launch_coop_no(gpe_engine* e, Batch& b, unsigned grid, size_t lds) {
 #define CARGS e->nd, e->theta, e->WpkT, b.pts, b.stored, b.Ob, e->gslab, b.n, b.ld, e->Ppad
+    if constexpr (HH <= 64) {
+        if (e->bwd_b6) {
+            switch (e->nd.n_lin - 2) {
+                case 1: hipLaunchKernelGGL((f_backward_coop<HH, CC, EE, NO, 1, true>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
+                case 2: hipLaunchKernelGGL((f_backward_coop<HH, CC, EE, NO, 2, true>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
+                default: hipLaunchKernelGGL((f_backward_coop<HH, CC, EE, NO, 3, true>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
+            }
+            return;
+        }
+    }
     switch (e->nd.n_lin - 2) {
         case 1: hipLaunchKernelGGL((f_backward_coop<HH, CC, EE, NO, 1>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
         case 2: hipLaunchKernelGGL((f_backward_coop<HH, CC, EE, NO, 2>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
@@ -926,7 +937,8 @@ int gpe_active_kernels(gpe_engine* e, char* buf, size_t n) {
         else snprintf(f, sizeof f, "f_forward<%d,%d,%d,%d,%s>", e->H, b.C, b.E, e->nd.n_out,
                       (e->H <= 64 && e->fwd_wlds && staged_batch(e, b)) ? "wlds" : "l2");
         const int kind = bwd_kind(e, b);
-        if (kind == 3) snprintf(r, sizeof r, "f_backward_coop<%d,%d,%d,%d,%d>", e->H, b.C, b.E, e->nd.n_out, maps > 5 ? 5 : maps);
+        if (kind == 3) snprintf(r, sizeof r, "f_backward_coop<%d,%d,%d,%d,%d%s>", e->H, b.C, b.E, e->nd.n_out, maps > 5 ? 5 : maps,
+                                (e->bwd_b6 && e->H <= 64) ? ",b6" : "");
         else if (kind == 2) snprintf(r, sizeof r, "f_backward<%d,%d,%d,%d,wlds,racc%d>", e->H, b.C, b.E, e->nd.n_out, maps > 3 ? 3 : maps);
         else snprintf(r, sizeof r, "f_backward<%d,%d,%d,%d,l2,%s>", e->H, b.C, b.E, e->nd.n_out, e->H > 64 ? "gacc" : "ldsacc");
     } else {
@@ -1038,7 +1050,7 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
         e->nslab = (H >= 128) ? std::max(e->nslab_g, e->num_cu) : e->num_cu * 2;     // H = 128: 16 atomic slabs, or one per workgroup (cooperative)
         if (e->wide) wide_init();
         // WpkT is followed by the bf16 pieces of the same maps (3 x 2 bytes per weight; pack_weight_element, f_forward_b6)
-        ok = alloc((void**)&e->Wpk, (size_t)(Lh - 1) * H * H * 4) && alloc((void**)&e->WpkT, (size_t)(Lh - 1) * H * H * (4 + 6)) &&
+        ok = alloc((void**)&e->Wpk, (size_t)(Lh - 1) * H * H * 4) && alloc((void**)&e->WpkT, (size_t)(Lh - 1) * H * H * (4 + 6 + 6)) &&
              alloc((void**)&e->gslab, (size_t)e->nslab * e->Ppad * 4);
         if (ok) {
             const int Cmain = dim + 2;        // training batches: value, dim first derivatives, Laplacian
@@ -1049,6 +1061,8 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
             e->fwd_wlds = want && H <= 64 && wb + smallb <= 64 * 1024;
             const char* envb6 = getenv("GPE_FWD_B6");                  // 1: f_forward_b6 for the large-batch forward pass at H <= 64
             e->fwd_b6 = envb6 && atoi(envb6) != 0 && H <= 64;
+            const char* envb7 = getenv("GPE_BWD_B6");                  // 1: the cooperative reverse kernel's adjoint products on the bf16 pipe
+            e->bwd_b6 = envb7 && atoi(envb7) != 0 && H <= 64 && H >= 32;
             const char* envc = getenv("GPE_COOP");
             e->coop = envc ? atoi(envc) : 1;          // measured: faster than the per-wave-tile kernels at every batch size
             const char* envm = getenv("GPE_COOP_MAX_TILES");
@@ -1074,6 +1088,9 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
     (void)hipFuncSetAttribute((const void*)f_backward_coop<HH, CC, EE, NO, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
     (void)hipFuncSetAttribute((const void*)f_backward_coop<HH, CC, EE, NO, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
     (void)hipFuncSetAttribute((const void*)f_backward_coop<HH, CC, EE, NO, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
+    (void)hipFuncSetAttribute((const void*)f_backward_coop<HH, CC, EE, NO, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
+    (void)hipFuncSetAttribute((const void*)f_backward_coop<HH, CC, EE, NO, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
+    (void)hipFuncSetAttribute((const void*)f_backward_coop<HH, CC, EE, NO, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
     (void)hipFuncSetAttribute((const void*)f_forward<HH, CC, EE, NO, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_f);      \
     (void)hipFuncSetAttribute((const void*)f_forward_b6<HH, CC, EE, NO, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)
 #ifdef GPE_FAST_BUILD

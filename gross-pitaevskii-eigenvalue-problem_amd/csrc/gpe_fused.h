@@ -73,6 +73,14 @@ GPE_DEV void pack_weight_element(const NetDesc& nd, int H, const float* __restri
         W6[o] = (unsigned short)(__builtin_bit_cast(unsigned, ph) >> 16);
         W6[o + per] = (unsigned short)(__builtin_bit_cast(unsigned, pm) >> 16);
         W6[o + 2 * (size_t)per] = (unsigned short)(__builtin_bit_cast(unsigned, pl) >> 16);
+        // ... and of the transposed maps for the adjoint products of f_backward_coop<..., B6> (behind W6):
+        //   WT6[j-1][piece][kt][kb][lane][e] = piece of W_j[32kb + 16(e>>2) + 4(lane>>4) + (e&3)][16kt + (lane&15)]     (t3 = kt * (NT/2) + kb)
+        unsigned short* WT6 = W6 + (size_t)(nd.n_lin - 2) * 3 * per;
+        const float wt = W[(32 * kb + 16 * (e8 >> 2) + 4 * (ln >> 4) + (e8 & 3)) * H + 16 * nt + (ln & 15)];
+        bf16_split3(wt, ph, pm, pl);
+        WT6[o] = (unsigned short)(__builtin_bit_cast(unsigned, ph) >> 16);
+        WT6[o + per] = (unsigned short)(__builtin_bit_cast(unsigned, pm) >> 16);
+        WT6[o + 2 * (size_t)per] = (unsigned short)(__builtin_bit_cast(unsigned, pl) >> 16);
     }
 }
 __global__ void k_pack_weights(NetDesc nd, int H, const float* __restrict__ theta, float* __restrict__ Wpk,
@@ -821,7 +829,11 @@ __global__ __launch_bounds__(H * 4, 2) void f_forward_coop(NetDesc nd, const flo
 // Elementwise work (recompute, activation adjoint), bias / output / layer-0 gradients are local to a slice.
 // Gradient slabs: H x H rows straight from the accumulators (each wave owns its rows: plain stores); small parameters via LDS.
 
-template <int H, int C, int E, int NOUT, int NHH>
+// B6 (opt-in, GPE_BWD_B6=1, H <= 64): the adjoint products W_j^T zbar_j as six bf16 matrix products on three-piece splits (see
+// f_forward_b6): every wave publishes the PIECES of its zbar fragment (24 B instead of 16 B per four values), the W^T pieces come
+// from L2 (six 1 KiB loads per map, requested before the barrier).  The weight-gradient products contract over the 16 POINTS of a
+// tile -- half a K = 32 slab -- and stay on the fp32 instruction.
+template <int H, int C, int E, int NOUT, int NHH, bool B6 = false>
 __global__ __launch_bounds__(H * 4, 2) void f_backward_coop(NetDesc nd, const float* __restrict__ theta,
                                                             const float* __restrict__ WpkT, Pts x,
                                                             const float* __restrict__ stored, const float* __restrict__ Ob,
@@ -836,7 +848,8 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_coop(NetDesc nd, const fl
     float* g0 = gsm + ((n_gsm + 3) & ~3);
     float* w0s = g0 + 4 * H;
     float* ZB = w0s + ((small_count(nd, H) + 3) & ~3);
-    float* XT = ZB + C * NT * 256;
+    constexpr int KB = NT / 2;
+    float* XT = ZB + (B6 ? 3 * C * KB * 256 : C * NT * 256);     // B6: [piece][C][KB][lane] x 16 B (two tiles' four bf16 values each)
     const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* TT = XT + C * NT * F_TILE + w * (C * F_TILE);
     const int dim = nd.dim;
@@ -849,9 +862,13 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_coop(NetDesc nd, const fl
     // this wave's K-slices of the transposed weights: A operands of  abar[16w..] = sum_nt W_j^T[16w.., 16nt..] z[16nt..].
     // H <= 64: register-resident for the whole kernel.  H = 128: streamed from L2 in chunks of NTC tiles, the first chunk
     // requested before the barrier that precedes its use.
-    constexpr bool WREG = (H <= 64);
+    static_assert(!B6 || H <= 64, "split-bf16 adjoint products: H <= 64");
+    constexpr bool WREG = (H <= 64) && !B6;
     constexpr int NTC = WREG ? NT : 4;
     const float* wbase = WpkT;
+    // B6: W^T pieces [map][piece][kt][kb][lane] x 16 B, behind WpkT and the forward pieces
+    const buf_t rW6 = buf_make(reinterpret_cast<const unsigned short*>(WpkT + (size_t)NHH * H * H) + (size_t)NHH * 3 * H * H,
+                               (unsigned)(NHH * 3 * H * H * 2));
     auto load_w = [&](int a, int nt) {
         return *reinterpret_cast<const f32x4*>(&wbase[(size_t)a * H * H + ((w * NT + nt) * 64 + lane) * 4]);
     };
@@ -962,12 +979,37 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_coop(NetDesc nd, const fl
             // own slice of z: transposed copy for the weight-gradient products (registers), fragment copy for everybody (LDS)
             f32x4 zt[C];
             tiles_transpose<C>(zb, zt, TT, m, q);
+            u32x4 wp6[B6 ? KB : 1][3];
+            if constexpr (B6) {
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                u32x2* Z6 = reinterpret_cast<u32x2*>(ZB);
 #pragma unroll
-            for (int c = 0; c < C; ++c) *reinterpret_cast<f32x4*>(&ZB[(c * NT + w) * 256 + lane * 4]) = zb[c];
+                for (int c = 0; c < C; ++c) {
+                    float hh[4], mm[4], ll[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bf16_split3(zb[c][r], hh[r], mm[r], ll[r]);
+                    const u32x2 ph = {bf16_pack2(zb[c][0], zb[c][1]), bf16_pack2(zb[c][2], zb[c][3])};
+                    const u32x2 pm = {bf16_pack2(mm[0], mm[1]), bf16_pack2(mm[2], mm[3])};
+                    const u32x2 pl = {bf16_pack2(ll[0], ll[1]), bf16_pack2(ll[2], ll[3])};
+                    // slot [piece][c][kb = w >> 1][lane]: 16 B = this tile pair's eight k slots of the lane; this wave fills half (w & 1)
+                    Z6[(((0 * C + c) * KB + (w >> 1)) * 64 + lane) * 2 + (w & 1)] = ph;
+                    Z6[(((1 * C + c) * KB + (w >> 1)) * 64 + lane) * 2 + (w & 1)] = pm;
+                    Z6[(((2 * C + c) * KB + (w >> 1)) * 64 + lane) * 2 + (w & 1)] = pl;
+                }
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc)
+                        wp6[kb][pc] = __builtin_bit_cast(u32x4, buf_load4(rW6, (unsigned)lane * 16u,
+                                                                          (unsigned)((((((j - 1) * 3 + pc) * NT + w) * KB) + kb) * 1024)));
+            } else {
+#pragma unroll
+                for (int c = 0; c < C; ++c) *reinterpret_cast<f32x4*>(&ZB[(c * NT + w) * 256 + lane * 4]) = zb[c];
+            }
             f32x4 st[C];
             load_st(j - 1, st);                                   // in flight across the barrier and the products below
             f32x4 wnext[NTC];
-            if constexpr (!WREG) {
+            if constexpr (!WREG && !B6) {
 #pragma unroll
                 for (int i = 0; i < NTC; ++i) wnext[i] = load_w(j - 1, i);
             }
@@ -980,8 +1022,26 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_coop(NetDesc nd, const fl
             f32x4 acc[C];
 #pragma unroll
             for (int c = 0; c < C; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (B6) {
+                const u32x4* Z6 = reinterpret_cast<const u32x4*>(ZB);
+                constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};     // smallest products first
 #pragma unroll
-            for (int nt0 = 0; nt0 < NT; nt0 += NTC) {
+                for (int kb = 0; kb < KB; ++kb) {
+                    u32x4 bp[C][3];
+#pragma unroll
+                    for (int c = 0; c < C; ++c)
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc) bp[c][pc] = Z6[((pc * C + c) * KB + kb) * 64 + lane];
+#pragma unroll
+                    for (int t = 0; t < 6; ++t)
+#pragma unroll
+                        for (int c = 0; c < C; ++c)
+                            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wp6[kb][PA[t]]),
+                                                                             __builtin_bit_cast(bf16x8, bp[c][PB[t]]), acc[c], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int nt0 = 0; nt0 < (B6 ? 0 : NT); nt0 += NTC) {
                 f32x4 wv[NTC];
 #pragma unroll
                 for (int i = 0; i < NTC; ++i) wv[i] = WREG ? wreg[WREG ? j - 1 : 0][WREG ? nt0 + i : 0] : wnext[i];

@@ -876,21 +876,26 @@ def test_wide_set_output_layer_fused_or_separate_agree():
     assert H.rel_err(res[0][1], res[1][1]) < 3e-6
 
 
+@pytest.mark.parametrize("mode", ["fwd", "bwd", "both"])
 @pytest.mark.parametrize("name", ["2d_64x4_g500", "1d_64x3_refine", "1d_32x4_nb_sym", "3d_64x3_aniso", "2d_64x3_complex_rot", "2d_N17_ragged"])
-def test_forward_b6_matches_oracle(name):
-    """GPE_FWD_B6=1 (opt-in): the H x H maps of the large-batch forward kernel as six bf16 matrix products per fp32 product (three bf16
-    pieces per operand, fp32 accumulation; f_forward_b6).  Same tolerances as the fp32-MFMA kernel: the split keeps 24 significant bits."""
+def test_split_bf16_kernels_match_oracle(name, mode):
+    """GPE_FWD_B6=1 / GPE_BWD_B6=1 (opt-in): the H x H maps of the large-batch forward kernel (f_forward_b6) and the adjoint products of
+    the cooperative reverse kernel (f_backward_coop<..., B6>) as six bf16 matrix products per fp32 product (three bf16 pieces per operand,
+    fp32 accumulation).  Same tolerances as the fp32-MFMA kernels: the split keeps 24 significant bits."""
     import os
     kw, N, _ = CASES[name]
     x, flat, x_bc = _inputs(kw, N, scale=_scale(kw))
     pb = go.Problem(**kw)
     osc, ograd, ores = go.full_loss_and_grad(pb, flat.astype(np.float64), x.astype(np.float64), x_bc.astype(np.float64))
-    old = {k: os.environ.get(k) for k in ("GPE_FWD_B6", "GPE_COOP_FWD_MAX_TILES")}
-    os.environ["GPE_FWD_B6"] = "1"
+    old = {k: os.environ.get(k) for k in ("GPE_FWD_B6", "GPE_BWD_B6", "GPE_COOP_FWD_MAX_TILES")}
+    os.environ["GPE_FWD_B6"] = "1" if mode in ("fwd", "both") else "0"
+    os.environ["GPE_BWD_B6"] = "1" if mode in ("bwd", "both") else "0"
     os.environ["GPE_COOP_FWD_MAX_TILES"] = "0"          # small batches would take the cooperative forward kernel
     try:
         eng = make_engine(pb, flat, x, x_bc, path=gpe_pinn.PATH_FUSED)
-        assert eng.active_kernels["fwd"].startswith("f_forward_b6<")
+        kern = eng.active_kernels
+        assert kern["fwd"].startswith("f_forward_b6<") == (mode in ("fwd", "both"))
+        assert kern["bwd"].endswith(",b6>") == (mode in ("bwd", "both")), kern
         rs, psi, res = eng.residual()
         assert close(psi.cpu().numpy(), ores["psi"], 5e-6, 2e-6)
         assert close(res.cpu().numpy(), ores["residual"], 2e-5, 1e-5)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""f_forward_b6 (six bf16 MFMA products per fp32 product) against the fp32-MFMA forward kernel and the fp64 oracle: one training step.
+"""f_forward_b6 / f_backward_coop<..., B6> (six bf16 MFMA products per fp32 product) against the fp32-MFMA kernels and the fp64 oracle: one training step.
 usage: [GPE_HIP_LIB=...] python tools/b6_check.py [N]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,15 +19,17 @@ pb = go.Problem(**kw)
 osc, ograd, _ = go.full_loss_and_grad(pb, flat.astype(np.float64), x.astype(np.float64), xb.astype(np.float64))
 os.environ["GPE_COOP_FWD_MAX_TILES"] = "0"
 res = {}
-for b6 in ("0", "1"):
+for b6, r6 in (("0", "0"), ("1", "0"), ("0", "1"), ("1", "1")):
     os.environ["GPE_FWD_B6"] = b6
+    os.environ["GPE_BWD_B6"] = r6
     eng = make_engine(pb, flat, x, xb, path=gpe_pinn.PATH_FUSED)
-    print("b6 =", b6, eng.active_kernels)
+    print("fwd b6 =", b6, " bwd b6 =", r6, eng.active_kernels)
     sc = eng.step()
     g = eng.get_grad()
-    res[b6] = (sc, g)
+    res[b6 + r6] = (sc, g)
     print("   loss %.8e (oracle %.8e, rel %.2e)  mu %.7f (oracle %.7f)  grad rel err vs oracle %.2e" %
           (sc["loss"], osc["loss"], abs(sc["loss"] - osc["loss"]) / abs(osc["loss"]), sc["mu"], osc["mu"], H.rel_err(g, ograd)))
     eng.close()
-print("b6 vs fp32 kernel: grad rel diff %.2e, loss rel diff %.2e" %
-      (H.rel_err(res["1"][1], res["0"][1]), abs(res["1"][0]["loss"] - res["0"][0]["loss"]) / abs(res["0"][0]["loss"])))
+for k in ("10", "01", "11"):
+    print("fwd/bwd b6 = %s vs fp32 kernels: grad rel diff %.2e, loss rel diff %.2e" %
+          (k, H.rel_err(res[k][1], res["00"][1]), abs(res[k][0]["loss"] - res["00"][0]["loss"]) / abs(res["00"][0]["loss"])))
