@@ -206,6 +206,40 @@ def load_profile_json(name):
     return None, None
 
 
+def split_bf16_mode(cfg, flat, x, xb, local_rank, args, n_local):
+    """The same workload, same steps, on the opt-in kernels that form every H x H product from six bf16 matrix products on three-piece
+    splits of both operands (GPE_FWD_B6=1 GPE_BWD_B6=1; fp32-equivalent results: DESIGN.md section 4, tests
+    test_split_bf16_kernels_match_oracle).  Reported next to the headline value, which stays on the fp32 matrix instruction."""
+    import gpe_pinn
+    os.environ["GPE_FWD_B6"] = "1"
+    os.environ["GPE_BWD_B6"] = "1"
+    try:
+        eng = gpe_pinn.Engine(cfg, device=local_rank)
+    finally:
+        os.environ.pop("GPE_FWD_B6", None)
+        os.environ.pop("GPE_BWD_B6", None)
+    try:
+        eng.set_params(flat)
+        eng.bind_points(torch.as_tensor(x, device=f"cuda:{local_rank}"))
+        eng.bind_boundary(torch.as_tensor(xb, device=f"cuda:{local_rank}"))
+        kernels = eng.active_kernels
+        eng.run(args.warmup)
+        eng.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.run(args.steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        sc = eng.read_scalars()
+    finally:
+        eng.close()
+    return {"switches": "GPE_FWD_B6=1 GPE_BWD_B6=1", "kernels": kernels, "value": n_local * args.steps / dt, "unit": "points/s",
+            "ms_per_step": dt / args.steps * 1e3, "steps": args.steps, "final_loss": sc["loss"], "mu_after_timed_steps": sc["mu"],
+            "note": "six v_mfma_f32_16x16x32_bf16 per fp32 product on three bf16 pieces per operand, fp32 accumulation; forward maps and "
+                    "the reverse pass's adjoint products (the weight-gradient products stay on v_mfma_f32_16x16x4_f32); the board runs "
+                    "about 9 % lower clocks in this mode (power limit)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,6 +252,7 @@ def main():
     ap.add_argument("--async-grad", action="store_true",
                     help="OPT-IN one-step-stale gradient: the gradient all-reduce overlaps the next forward (changes the trajectory; labelled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt-mode", action="store_true", help="skip the second timed pass on the split-bf16 kernels (H <= 64 workloads)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -368,6 +403,9 @@ def main():
                                "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS,
                                "traffic": None, "algorithmic_flop_per_point": flops_pt, "avg_launch_ms": elapsed / args.steps * 1e3}
             out.pop("roofline_forward", None)
+        if world == 1 and fused and not args.no_alt_mode and max(layers[1:-1]) <= 64 and not os.environ.get("GPE_FWD_B6") \
+                and not os.environ.get("GPE_BWD_B6"):
+            out["split_bf16_mode"] = split_bf16_mode(cfg, flat, x, xb, local_rank, args, n_local)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, flat)
             out["cpu_baseline_native"] = cpu_baseline_native(wl, flat)

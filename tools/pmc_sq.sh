@@ -10,7 +10,7 @@ R=$PWD
 mkdir -p $out
 export TMPDIR=/tmp
 cd /tmp
-CMD="python3 $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline"
+CMD="python3 $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-alt-mode"
 pass() {   # name, counters...
     name=$1; shift
     rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out/pmc_$name -- $CMD > /dev/null 2> $out/pmc_$name.err || { echo "pass $name failed"; tail -5 $out/pmc_$name.err; return 1; }
@@ -24,5 +24,5 @@ pass write WRITE_SIZE
 cd $R
 python3 tools/pmc_sq_summary.py $out/mfma_util_$wl.json "$CMD" $out/pmc_a/*/*counter_collection.csv $out/pmc_b/*/*counter_collection.csv $out/pmc_c/*/*counter_collection.csv
 python3 tools/pmc_traffic.py $out/pmc_fetch/*/*counter_collection.csv $out/pmc_write/*/*counter_collection.csv $pts $out/traffic_$wl.json \
-  "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline"
+  "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-alt-mode"
 rm -rf $out/pmc_a $out/pmc_b $out/pmc_c $out/pmc_fetch $out/pmc_write

@@ -8,7 +8,7 @@ R=$PWD
 export TMPDIR=/tmp
 for wl in ns_2d_4x64 cfg5_3d_6x256; do
   d=$(mktemp -d /tmp/ks.XXXX)
-  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 $R/bench.py --workload $wl --steps 10 --warmup 3 --no-cpu-baseline > $R/$out/bench_${wl}_under_rocprof.json 2> $R/$out/stats_$wl.err)
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 $R/bench.py --workload $wl --steps 10 --warmup 3 --no-cpu-baseline --no-alt-mode > $R/$out/bench_${wl}_under_rocprof.json 2> $R/$out/stats_$wl.err)
   cp $d/*/*kernel_stats.csv $out/kernel_stats_$wl.csv; rm -rf $d
   echo "stats $wl done"
 done
