@@ -62,7 +62,7 @@ GPE_DEV void pack_weight_element(const NetDesc& nd, int H, const float* __restri
     WpkT[idx] = W[(16 * b + 4 * q + s) * H + 16 * a + i];          // a = kt, b = nt
     // bf16 pieces for f_forward_b6 (behind WpkT in the same allocation):
     //   W6[j-1][piece][nt][kb][lane][e] = piece of W_j[16nt + (lane&15)][32kb + 16(e>>2) + 4(lane>>4) + (e&3)],  W = hi + mid + lo
-    {
+    if (H <= 64) {                                                  // (the kernels that read the pieces exist for H <= 64)
         unsigned short* W6 = reinterpret_cast<unsigned short*>(WpkT + (size_t)(nd.n_lin - 2) * per);
         const int e8 = e & 7, ln = (e >> 3) & 63, t3 = e >> 9;     // t3 = nt * (NT/2) + kb
         const int nt = t3 / (NT / 2), kb = t3 % (NT / 2);
