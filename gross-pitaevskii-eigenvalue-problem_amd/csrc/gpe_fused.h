@@ -37,6 +37,9 @@
 #ifndef GPE_COOP_PRIO
 #define GPE_COOP_PRIO 1      // s_setprio level of the product phases of f_backward_coop (H <= 64); 0 switches it off
 #endif
+#ifndef GPE_COOP_PRIO_P
+#define GPE_COOP_PRIO_P 0    // ... and of its VALU / LDS phases
+#endif
 
 // pack hidden-hidden weights (linear maps 1..L-1) in MFMA fragment order.
 //   Wpk [j-1][nt][kt][lane][s] = W_j[16nt + (lane&15)][16kt + 4(lane>>4) + s]      (forward A operand)
@@ -941,8 +944,12 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_coop(NetDesc nd, const fl
                     f32x4 g = SREG ? gwoacc[o] : (f32x4)(0.f);
 #pragma unroll
                     for (int c = 0; c < C; ++c) g = gpe_fma((f32x4)(ob[o][c]), a4[c], g);
-                    if constexpr (SREG) gwoacc[o] = g;
-                    else {
+                    if constexpr (SREG) {
+                        // pin the sum here: left free, the scheduler sinks these adds below the last map of the tile and keeps the
+                        // recomputed jets alive (and in scratch) across all the product phases
+                        asm volatile("" : "+v"(g));
+                        gwoacc[o] = g;
+                    } else {
                         const float gv[4] = {g[0], g[1], g[2], g[3]};
                         row_reduce4_add(gv, &gsm[(L - 1 + o) * H + 16 * w], m, q);
                     }
@@ -1063,7 +1070,7 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_coop(NetDesc nd, const fl
                             acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i][s2], bf[c][s2], acc[c], 0, 0, 0);
                 }
             }
-            if constexpr (H <= 64) __builtin_amdgcn_s_setprio(0);
+            if constexpr (H <= 64) __builtin_amdgcn_s_setprio(GPE_COOP_PRIO_P);
             if constexpr (!WREG) __builtin_amdgcn_sched_barrier(0);      // keep the phases' live ranges apart (256-register budget)
             // recompute X of layer j-1 (own slice), activation adjoint -> z of layer j-1, X^T into the shared buffer
             f32x4 xa[C];
@@ -1072,7 +1079,7 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_coop(NetDesc nd, const fl
 #pragma unroll
             for (int c = 0; c < C; ++c)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) XT[(c * NT + w) * F_TILE + (4 * q + r) * F_PITCH + m] = xa[c][r];
+                for (int r = 0; r < 4; ++r) XT[(c * NT + w) * F_TILE + (4 * q + r) * F_PITCH + tr_wcol(m, q)] = xa[c][r];
             __syncthreads();
             // dW_j[rows of this slice][all columns] += Z^T X : NT independent accumulator chains
             if constexpr (!WREG) __builtin_amdgcn_sched_barrier(0);
@@ -1085,7 +1092,7 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_coop(NetDesc nd, const fl
                     f32x4 xf[KTC];
 #pragma unroll
                     for (int i = 0; i < KTC; ++i)
-                        xf[i] = *reinterpret_cast<const f32x4*>(&XT[(c * NT + kt0 + i) * F_TILE + m * F_PITCH + 4 * q]);
+                        xf[i] = *reinterpret_cast<const f32x4*>(&XT[(c * NT + kt0 + i) * F_TILE + tr_roff(m, q)]);
 #pragma unroll
                     for (int s2 = 0; s2 < 4; ++s2)
 #pragma unroll
@@ -1093,7 +1100,7 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_coop(NetDesc nd, const fl
                             dwacc[j - 1][kt0 + i] =
                                 __builtin_amdgcn_mfma_f32_16x16x4f32(zt[c][s2], xf[i][s2], dwacc[j - 1][kt0 + i], 0, 0, 0);
                 }
-            if constexpr (H <= 64) __builtin_amdgcn_s_setprio(0);
+            if constexpr (H <= 64) __builtin_amdgcn_s_setprio(GPE_COOP_PRIO_P);
         }
         // ---- linear map 0, own slice: g0[k][n] (k < dim: dW0[n][k]; k = 3: db0[n]) ---------------------------------------------
         {
@@ -1116,6 +1123,304 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_coop(NetDesc nd, const fl
             }
         }
     }
+    // ---- the per-lane sums: across the 16 point lanes, into the workgroup's LDS block (zeroed above; every wave owns its rows) --------
+    if constexpr (SREG) {
+        auto reduce4 = [&](const f32x4& a, float* dst16) {
+            const float v[4] = {a[0], a[1], a[2], a[3]};
+            row_reduce4_add(v, dst16, m, q);
+        };
+#pragma unroll
+        for (int a = 0; a < NHH; ++a) reduce4(dbacc[a], &gsm[a * H + 16 * w]);
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) reduce4(gwoacc[o], &gsm[(L - 1 + o) * H + 16 * w]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) reduce4(g0acc[k], &g0[k * H + 16 * w]);
+        if (w == 0) {
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) {
+                const float gbo = row_sum16(gboacc[o]);
+                if (lane == 0) atomicAdd(&gsm[(L - 1 + NOUT) * H + o], gbo);
+            }
+        }
+    }
+    // ---- slab: H x H rows from the accumulators, the rest from LDS ---------------------------------------------------------
+    float* slab = gslab + (size_t)blockIdx.x * Ppad;
+#pragma unroll
+    for (int a = 0; a < NHH; ++a)
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slab[nd.offW[a + 1] + (16 * w + 4 * q + r) * H + 16 * kt + m] = dwacc[a][kt][r];
+    __syncthreads();
+    for (int i = threadIdx.x; i < (L - 1) * H; i += NTHR) slab[nd.offB[1 + i / H] + i % H] = gsm[i];
+    for (int i = threadIdx.x; i < NOUT * H; i += NTHR) slab[nd.offW[L] + i] = gsm[(L - 1) * H + i];
+    for (int i = threadIdx.x; i < NOUT; i += NTHR) slab[nd.offB[L] + i] = gsm[(L - 1 + NOUT) * H + i];
+    for (int i = threadIdx.x; i < 4 * H; i += NTHR) {
+        const int n = i % H, k = i / H;
+        if (k == 3) slab[nd.offB[0] + n] = g0[i];
+        else if (k < dim) slab[nd.offW[0] + n * dim + k] = g0[i];
+    }
+}
+
+// ---- pipelined cooperative reverse kernel (H <= 64; the default reverse kernel there) ---------------------------------------
+// Same decomposition as f_backward_coop -- a workgroup of NT = H/16 waves per 16-point tile, wave w owns the feature slice 16w..16w+15,
+// its K-slices of every W_j^T and its rows of every dW_j stay in registers -- with ONE workgroup barrier per hidden->hidden map
+// instead of two.  The weight-gradient product of map j (dW_j += Z_j X_{j-1}^T) feeds nothing downstream, so it is deferred by one
+// barrier interval and runs back to back with the adjoint product of map j-1 (abar_{j-2} = W_{j-1}^T z_{j-1}); across the tile
+// boundary the dW_1 product of tile t runs with the first adjoint product of tile t+1.  Every interval is then
+//     barrier | 2 x 16 C NT matrix instructions (4096 cycles for NS) | recompute + activation adjoint + publish (VALU / LDS) |
+// i.e. NHH barriers per tile instead of 2 NHH, each product phase twice as long: the fixed cost of an interval (LDS latency of the
+// first operands, barrier skew between the SIMDs) is paid half as often.  The z and X^T exchange buffers are double-buffered (the
+// waves of a workgroup are up to one interval apart).  No transposition scratch and no transposed copy of z in registers: the
+// feature-on-lane operand of the deferred product is read back from the wave's OWN slice of the z buffer written two intervals
+// earlier (nobody else writes it, and the wave itself only overwrites it later in the same interval) with sixteen ds_read_b32 --
+// conflict-free because the 16-byte fragment slots of that buffer are XOR-swizzled (slot of lane (m, q) = (m ^ q) + 16 q: the
+// ds_read_b128 lane groups still cover each bank row once, and the 32 lanes of a b32 read group land on 32 distinct banks).
+// LDS: 2 x (C NT 256) x 2 x 4 B = 64 KB for NS, two workgroups per CU.
+template <int H, int C, int E, int NOUT, int NHH>
+__global__ __launch_bounds__(H * 4, 2) void f_backward_pipe(NetDesc nd, const float* __restrict__ theta,
+                                                            const float* __restrict__ WpkT, Pts x,
+                                                            const float* __restrict__ stored, const float* __restrict__ Ob,
+                                                            float* __restrict__ gslab, int64_t N, int64_t ld, int Ppad) {
+    constexpr int D = C - 1 - E, NT = H / 16, NTHR = 64 * NT;
+    constexpr int L = NHH + 1;                       // index of the output map; hidden layers 0..L-1
+    constexpr int ZSZ = C * NT * 256;                // floats per exchange buffer (z fragments and X^T tiles alike: F_TILE = 256)
+    static_assert(H <= 64 && F_TILE == 256, "register-resident weights; 16 x 16 exchange tiles");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // LDS: gsm (small-parameter gradients) | g0[4][H] | w0s small operands | ZB[2][C][NT][256] | XT[2][C][NT][256]
+    const int n_gsm = (L - 1 + NOUT) * H + 4;        // b_1..b_{L-1} | W_out[NOUT][H] | b_out
+    float* gsm = lds;
+    float* g0 = gsm + ((n_gsm + 3) & ~3);
+    float* w0s = g0 + 4 * H;
+    float* ZB = w0s + ((small_count(nd, H) + 3) & ~3);
+    float* XT = ZB + 2 * ZSZ;
+    const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int dim = nd.dim;
+    const float shift = nd.shift;
+    const int64_t ntiles = (N + 15) >> 4;
+    const float* Wo = w0s + (4 + L - 1) * H;
+    const int zfrag = 4 * ((m ^ q) + 16 * q);          // float offset of the lane's fragment slot in a 256-float z tile (swizzled)
+    // ... and of element (feature m, point 4q+s) of such a tile, s = 0..3: the transposed read of the deferred product
+    int ztr[4];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) ztr[s2] = 4 * (((4 * q + s2) ^ (m >> 2)) + 16 * (m >> 2)) + (m & 3);
+
+    for (int i = threadIdx.x; i < ((n_gsm + 3) & ~3) + 4 * H; i += NTHR) gsm[i] = 0.f;      // gsm and g0 are contiguous
+    stage_layer0<H>(w0s, theta, nd, NTHR);
+    f32x4 wreg[NHH][NT];                               // K-slices of W_j^T: A operands of abar[16w..] = sum_nt W_j^T[16w.., 16nt..] z[16nt..]
+#pragma unroll
+    for (int a = 0; a < NHH; ++a)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            wreg[a][nt] = *reinterpret_cast<const f32x4*>(&WpkT[(size_t)a * H * H + ((w * NT + nt) * 64 + lane) * 4]);
+    f32x4 dwacc[NHH][NT];                              // rows 16w..16w+15 of dW_j, column tile kt
+#pragma unroll
+    for (int a = 0; a < NHH; ++a)
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) dwacc[a][kt] = (f32x4)(0.f);
+    // small-parameter gradients of this wave's slice: per-lane sums over all tiles (see f_backward_coop), or per-tile reductions
+    constexpr bool SREG = (C * NHH <= 12);
+    f32x4 dbacc[NHH], g0acc[4], gwoacc[NOUT];
+    float gboacc[NOUT];
+#pragma unroll
+    for (int a = 0; a < NHH; ++a) dbacc[a] = (f32x4)(0.f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g0acc[k] = (f32x4)(0.f);
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) { gwoacc[o] = (f32x4)(0.f); gboacc[o] = 0.f; }
+    __syncthreads();
+
+    // ---- pieces of a tile's work ---------------------------------------------------------------------------------------------
+    float xv[3] = {0.f, 0.f, 0.f};
+    float ob[NOUT][C];
+    auto load_point = [&](int64_t tile) {              // coordinates and output-jet adjoints of the lane's point
+        const int64_t pm = tile * 16 + m;
+        const bool valid = pm < N;
+        const int64_t pl = valid ? pm : N - 1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) if (k < dim) xv[k] = pts_at(x, pl, dim, k);
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+            for (int c = 0; c < C; ++c) ob[o][c] = valid ? Ob[((int64_t)c * NOUT + o) * ld + pm] : 0.f;
+    };
+    // stored (t, z_k, z_L) of hidden layer h >= 1 of a tile, this wave's slice: the tile's block [L-1][C][NT][256] behind one descriptor
+    auto load_st = [&](int64_t tile, int h, f32x4 (&st)[C]) {
+        const buf_t rS = buf_make(stored + (size_t)tile * (L - 1) * C * NT * 256, (unsigned)((L - 1) * C * NT * 1024));
+#pragma unroll
+        for (int c = 0; c < C; ++c) st[c] = buf_load4(rS, (unsigned)lane * 16u, (unsigned)((((h - 1) * C + c) * NT + w) * 1024));
+    };
+    // z of a map's output, own slice, into the write-side buffer: B operand of everybody's adjoint product after the next barrier
+    auto publish_z = [&](const f32x4 (&zb)[C], float* zw) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) *reinterpret_cast<f32x4*>(&zw[(c * NT + w) * 256 + zfrag]) = zb[c];
+    };
+    // output map of a tile (own slice): its weight / bias gradients and z of the top hidden layer
+    auto output_stage = [&](const f32x4 (&st)[C], f32x4 (&zb)[C]) {
+        f32x4 wo[NOUT];
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) wo[o] = *reinterpret_cast<const f32x4*>(&Wo[o * H + 16 * w + 4 * q]);
+        f32x4 a4[C], ab4[C];
+        act_from_stored<D, E>(st[0], st + 1, st + 1 + D, shift, a4);
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+            f32x4 g = SREG ? gwoacc[o] : (f32x4)(0.f);
+#pragma unroll
+            for (int c = 0; c < C; ++c) g = gpe_fma((f32x4)(ob[o][c]), a4[c], g);
+            if constexpr (SREG) {
+                asm volatile("" : "+v"(g));            // pin the sum here (else the recomputed jets stay alive across the product phases)
+                gwoacc[o] = g;
+            } else {
+                const float gv[4] = {g[0], g[1], g[2], g[3]};
+                row_reduce4_add(gv, &gsm[(L - 1 + o) * H + 16 * w], m, q);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            f32x4 v = (f32x4)(0.f);
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) v = gpe_fma(wo[o], (f32x4)(ob[o][c]), v);
+            ab4[c] = v;
+        }
+        act_adjoint<D, E>(st[0], st + 1, st + 1 + D, ab4, zb);
+        if constexpr (SREG) {
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) gboacc[o] += ob[o][0];      // (every q-row of lanes holds the same 16 points)
+        } else if (w == 0) {
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) {
+                const float gbo = row_sum16(ob[o][0]);
+                if (lane == 0) atomicAdd(&gsm[(L - 1 + NOUT) * H + o], gbo);
+            }
+        }
+    };
+    auto bias_sum = [&](const f32x4& z0, int a) {      // bias gradient of map a+1, own slice
+        if constexpr (SREG) dbacc[a] += z0;
+        else {
+            const float v[4] = {z0[0], z0[1], z0[2], z0[3]};
+            row_reduce4_add(v, &gsm[a * H + 16 * w], m, q);
+        }
+    };
+    // dW[rows of this slice][all columns] += Z^T X : NT independent accumulator chains.  zo: the z buffer that holds this map's z
+    // (own slice read feature-on-lane), xr: the X^T tiles of its input layer
+    auto wgrad_products = [&](f32x4 (&dw)[NT], const float* zo, const float* xr) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            f32x4 zt;
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) zt[s2] = zo[(c * NT + w) * 256 + ztr[s2]];
+            f32x4 xf[NT];
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) xf[kt] = *reinterpret_cast<const f32x4*>(&xr[(c * NT + kt) * 256 + tr_roff(m, q)]);
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) dw[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(zt[s2], xf[kt][s2], dw[kt], 0, 0, 0);
+        }
+    };
+
+    // ---- first tile: output map, z of the top hidden layer into buffer 0 ------------------------------------------------------------
+    int64_t tile = blockIdx.x;
+    int par = 0;                                       // exchange buffers the next product phase READS
+    f32x4 st[C];                                       // stored jets in flight for the next activation adjoint
+    bool have_pend = false;                            // map 1 of the previous tile waits for its dW product
+    if (tile < ntiles) {
+        load_point(tile);
+        f32x4 stl[C], zb[C];
+        if constexpr (L - 1 >= 1) load_st(tile, L - 1, stl); else layer0_st<H, C, E>(w0s, xv, w, q, stl);
+        output_stage(stl, zb);
+        bias_sum(zb[0], NHH - 1);
+        publish_z(zb, ZB);
+        if constexpr (NHH - 1 >= 1) load_st(tile, NHH - 1, st);
+    }
+    for (; tile < ntiles; tile += gridDim.x) {
+        const bool have_next = tile + gridDim.x < ntiles;
+        float xv_t[3] = {xv[0], xv[1], xv[2]};         // this tile's coordinates (layer 0 recompute, layer-0 gradients)
+#pragma unroll
+        for (int j = NHH; j >= 1; --j) {
+            const float* zr = ZB + par * ZSZ;          // read side (filled in the previous interval)
+            const float* xr = XT + par * ZSZ;
+            float* zw = ZB + (par ^ 1) * ZSZ;          // write side; its z tiles are two intervals old until this interval's publish
+            float* xw = XT + (par ^ 1) * ZSZ;
+            f32x4 stn[C];                              // next tile's top-layer stored jets (requested in the tile's last interval)
+            __syncthreads();
+            if (j == 1 && have_next) {
+                load_point(tile + gridDim.x);
+                if constexpr (L - 1 >= 1) load_st(tile + gridDim.x, L - 1, stn);
+            }
+            __builtin_amdgcn_s_setprio(GPE_COOP_PRIO);
+            // abar (own slice) = sum_nt W_j^T[slice, nt] z[nt] : C independent accumulator chains
+            f32x4 acc[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] = (f32x4)(0.f);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 bf[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) bf[c] = *reinterpret_cast<const f32x4*>(&zr[(c * NT + nt) * 256 + zfrag]);
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                    for (int c = 0; c < C; ++c)
+                        acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j - 1][nt][s2], bf[c][s2], acc[c], 0, 0, 0);
+            }
+            // deferred weight-gradient product: map j+1 of this tile, or map 1 of the previous tile
+            if (j == NHH) { if (have_pend) wgrad_products(dwacc[0], zw, xr); }
+            else wgrad_products(dwacc[j < NHH ? j : 0], zw, xr);
+            __builtin_amdgcn_s_setprio(GPE_COOP_PRIO_P);
+            // recompute X of layer j-1 (own slice), activation adjoint -> z of layer j-1, X^T into the write-side buffer
+            f32x4 sj[C];
+            if (j - 1 >= 1) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) sj[c] = st[c];
+            } else layer0_st<H, C, E>(w0s, xv_t, w, q, sj);
+            f32x4 xa[C], zb[C];
+            act_from_stored<D, E>(sj[0], sj + 1, sj + 1 + D, shift, xa);
+            act_adjoint<D, E>(sj[0], sj + 1, sj + 1 + D, acc, zb);
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xw[(c * NT + w) * 256 + (4 * q + r) * F_PITCH + tr_wcol(m, q)] = xa[c][r];
+            if (j > 1) {
+                bias_sum(zb[0], j - 2);
+                publish_z(zb, zw);
+                if (j - 2 >= 1) load_st(tile, j - 2, st);
+            } else {
+                // ---- linear map 0, own slice: g0[k][n] (k < dim: dW0[n][k]; k = 3: db0[n]) ----------------------------------------
+                if constexpr (SREG) g0acc[3] += zb[0];
+                else {
+                    const float z0[4] = {zb[0][0], zb[0][1], zb[0][2], zb[0][3]};
+                    row_reduce4_add(z0, &g0[3 * H + 16 * w], m, q);
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    if (k < D || (D == 0 && k < dim)) {
+                        f32x4 v = zb[0] * xv_t[k];
+                        if constexpr (C > 1) { if (k < D) v += zb[(1 + k) < C ? (1 + k) : 0]; }
+                        if constexpr (SREG) g0acc[k] += v;
+                        else {
+                            const float vv[4] = {v[0], v[1], v[2], v[3]};
+                            row_reduce4_add(vv, &g0[k * H + 16 * w], m, q);
+                        }
+                    }
+                }
+                have_pend = true;                      // map 1's X^T is on the write side: its product runs behind the next barrier
+                // ---- next tile: output map, z of its top hidden layer --------------------------------------------------------------
+                if (have_next) {
+                    f32x4 zn[C];
+                    if constexpr (L - 1 >= 1) output_stage(stn, zn);
+                    else { f32x4 s0[C]; layer0_st<H, C, E>(w0s, xv, w, q, s0); output_stage(s0, zn); }
+                    bias_sum(zn[0], NHH - 1);
+                    publish_z(zn, zw);
+                    if constexpr (NHH - 1 >= 1) load_st(tile + gridDim.x, NHH - 1, st);
+                }
+            }
+            par ^= 1;
+        }
+    }
+    // ---- the last tile's deferred dW_1 product ----------------------------------------------------------------------------------
+    __syncthreads();
+    if (have_pend) wgrad_products(dwacc[0], ZB + (par ^ 1) * ZSZ, XT + par * ZSZ);
     // ---- the per-lane sums: across the 16 point lanes, into the workgroup's LDS block (zeroed above; every wave owns its rows) --------
     if constexpr (SREG) {
         auto reduce4 = [&](const f32x4& a, float* dst16) {

@@ -516,7 +516,7 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
 #pragma unroll
         for (int c = 0; c < C; ++c)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) XT[(c * KTL + w) * F_TILE + (4 * q + r) * F_PITCH + m] = xa[c][r];
+            for (int r = 0; r < 4; ++r) XT[(c * KTL + w) * F_TILE + (4 * q + r) * F_PITCH + tr_wcol(m, q)] = xa[c][r];
         if (tile + G < ntiles) issue_loads(tile + G);            // next tile's loads: in flight behind the products below
         __builtin_amdgcn_sched_barrier(0);
         WSTAMP(5);
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
                 f32x4 xf[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    xf[i] = *reinterpret_cast<const f32x4*>(&XT[(c * KTL + k0 + i) * F_TILE + m * F_PITCH + 4 * q]);
+                    xf[i] = *reinterpret_cast<const f32x4*>(&XT[(c * KTL + k0 + i) * F_TILE + tr_roff(m, q)]);
 #pragma unroll
                 for (int s2 = 0; s2 < 4; ++s2)
 #pragma unroll
