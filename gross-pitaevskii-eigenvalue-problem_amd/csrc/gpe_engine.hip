@@ -239,6 +239,8 @@ struct gpe_engine {
     bool fwd_wlds = false;                        // forward kernel stages the hidden-hidden weights in LDS
     bool fwd_b6 = false;                          // f_forward_b6: H x H maps as six bf16 MFMA products per fp32 product (H <= 64; GPE_FWD_B6)
     bool bwd_b6 = false;                          // f_backward_coop<..., B6>: the adjoint products the same way (H <= 64; GPE_BWD_B6)
+    int coop_wg_per_cu = 2;                       // cooperative reverse kernels at H <= 64: persistent workgroups per CU (tuning: GPE_COOP_WG_PER_CU)
+    bool bwd_pipe = true;                         // cooperative reverse kernel in its one-barrier-per-map form (f_backward_pipe; H <= 64; GPE_PIPE)
     bool bwd_racc = false;                        // reverse kernel keeps the H x H weight gradients in registers (1 wave/SIMD)
     int nslab_g = 16;                             // H = 128: number of global-atomic gradient slabs
     int coop = 1;                                 // cooperative reverse kernel: 0 never, 1 whenever compiled for the shape, -1 by batch size
@@ -500,11 +502,29 @@ static int bwd_kind(gpe_engine* e, const Batch& b) {
     if (e->H > 64 || !staged_batch(e, b)) return 0;
     return e->bwd_racc ? 2 : 0;
 }
+// f_backward_pipe: two z and two X^T exchange buffers; taken when two workgroups per CU still fit
+static size_t pipe_lds(gpe_engine* e, int C) {
+    const int H = e->H, NT = H / 16, L = e->nd.n_lin - 1;
+    const size_t n_gsm = ((size_t)(L - 1 + e->nd.n_out) * H + 4 + 3) & ~(size_t)3;
+    return (n_gsm + 4 * (size_t)H) * sizeof(float) + fused_small_bytes(e) + (size_t)4 * C * NT * 256 * sizeof(float);
+}
+static bool use_pipe(gpe_engine* e, int C) {
+    return e->bwd_pipe && !e->bwd_b6 && e->H <= 64 && e->nd.n_lin - 2 >= 1 && e->nd.n_lin - 2 <= 3 && 2 * (pipe_lds(e, C) + 1024) <= (size_t)160 * 1024;
+}
 static size_t coop_lds(gpe_engine* e, int C) {
+    if (use_pipe(e, C)) return pipe_lds(e, C);
     const int H = e->H, NT = H / 16, L = e->nd.n_lin - 1;
     const size_t n_gsm = ((size_t)(L - 1 + e->nd.n_out) * H + 4 + 3) & ~(size_t)3;
     const size_t zb = e->bwd_b6 && H <= 64 ? (size_t)3 * C * (NT / 2) * 256 : (size_t)C * NT * 256;     // B6: three bf16 pieces, 24 B per four values
     return (n_gsm + 4 * (size_t)H) * sizeof(float) + fused_small_bytes(e) + (zb + 2 * (size_t)C * NT * F_TILE) * sizeof(float);
+}
+template <int HH, int CC, int EE, int NO>
+static void set_pipe_lds(int bytes) {
+    if constexpr (!(HH == 64 && CC == 5)) {
+        (void)hipFuncSetAttribute((const void*)f_backward_pipe<HH, CC, EE, NO, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        (void)hipFuncSetAttribute((const void*)f_backward_pipe<HH, CC, EE, NO, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        (void)hipFuncSetAttribute((const void*)f_backward_pipe<HH, CC, EE, NO, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    }
 }
 template <int HH, int CC, int EE, int NO>
 static void launch_coop_no(gpe_engine* e, Batch& b, unsigned grid, size_t lds) {
@@ -515,6 +535,14 @@ static void launch_coop_no(gpe_engine* e, Batch& b, unsigned grid, size_t lds) {
                 case 1: hipLaunchKernelGGL((f_backward_coop<HH, CC, EE, NO, 1, true>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
                 case 2: hipLaunchKernelGGL((f_backward_coop<HH, CC, EE, NO, 2, true>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
                 default: hipLaunchKernelGGL((f_backward_coop<HH, CC, EE, NO, 3, true>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
+            }
+            return;
+        }
+        if constexpr (!(HH == 64 && CC == 5)) if (use_pipe(e, CC)) {       // (H = 64 in 3D: two workgroups' exchange buffers exceed the LDS)
+            switch (e->nd.n_lin - 2) {
+                case 1: hipLaunchKernelGGL((f_backward_pipe<HH, CC, EE, NO, 1>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
+                case 2: hipLaunchKernelGGL((f_backward_pipe<HH, CC, EE, NO, 2>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
+                default: hipLaunchKernelGGL((f_backward_pipe<HH, CC, EE, NO, 3>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
             }
             return;
         }
@@ -706,7 +734,7 @@ static int mlp_backward(gpe_engine* e, Batch& b, bool close = false, bool assign
     if (b.n <= 0) return close ? launch_tail(e, true) : GPE_OK;
     if (e->path == GPE_PATH_FUSED) {
         const int kind = bwd_kind(e, b);
-        unsigned grid = kind == 3 ? fused_grid(e, b.n, 1, 2)
+        unsigned grid = kind == 3 ? fused_grid(e, b.n, 1, e->coop_wg_per_cu)
                                   : (kind == 2 ? fused_grid(e, b.n, 4, 1) : fused_grid(e, b.n, 4, 2));
         size_t lds = kind == 3 ? coop_lds(e, b.C) : fused_bwd_lds(e, b.C, kind);
         const bool mark = e->prof && (&b == &e->main);
@@ -937,7 +965,8 @@ int gpe_active_kernels(gpe_engine* e, char* buf, size_t n) {
         else snprintf(f, sizeof f, "f_forward<%d,%d,%d,%d,%s>", e->H, b.C, b.E, e->nd.n_out,
                       (e->H <= 64 && e->fwd_wlds && staged_batch(e, b)) ? "wlds" : "l2");
         const int kind = bwd_kind(e, b);
-        if (kind == 3) snprintf(r, sizeof r, "f_backward_coop<%d,%d,%d,%d,%d%s>", e->H, b.C, b.E, e->nd.n_out, maps > 5 ? 5 : maps,
+        if (kind == 3 && use_pipe(e, b.C)) snprintf(r, sizeof r, "f_backward_pipe<%d,%d,%d,%d,%d>", e->H, b.C, b.E, e->nd.n_out, maps);
+        else if (kind == 3) snprintf(r, sizeof r, "f_backward_coop<%d,%d,%d,%d,%d%s>", e->H, b.C, b.E, e->nd.n_out, maps > 5 ? 5 : maps,
                                 (e->bwd_b6 && e->H <= 64) ? ",b6" : "");
         else if (kind == 2) snprintf(r, sizeof r, "f_backward<%d,%d,%d,%d,wlds,racc%d>", e->H, b.C, b.E, e->nd.n_out, maps > 3 ? 3 : maps);
         else snprintf(r, sizeof r, "f_backward<%d,%d,%d,%d,l2,%s>", e->H, b.C, b.E, e->nd.n_out, e->H > 64 ? "gacc" : "ldsacc");
@@ -1063,6 +1092,10 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
             e->fwd_b6 = envb6 && atoi(envb6) != 0 && H <= 64;
             const char* envb7 = getenv("GPE_BWD_B6");                  // 1: the cooperative reverse kernel's adjoint products on the bf16 pipe
             e->bwd_b6 = envb7 && atoi(envb7) != 0 && H <= 64 && H >= 32;
+            const char* envp = getenv("GPE_PIPE");                     // 0: the two-barrier cooperative reverse kernel (f_backward_coop) at H <= 64
+            e->bwd_pipe = !envp || atoi(envp) != 0;
+            const char* envw = getenv("GPE_COOP_WG_PER_CU");
+            if (envw && atoi(envw) >= 1 && atoi(envw) <= 2) e->coop_wg_per_cu = atoi(envw);
             const char* envc = getenv("GPE_COOP");
             e->coop = envc ? atoi(envc) : 1;          // measured: faster than the per-wave-tile kernels at every batch size
             const char* envm = getenv("GPE_COOP_MAX_TILES");
@@ -1088,6 +1121,7 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
     (void)hipFuncSetAttribute((const void*)f_backward_coop<HH, CC, EE, NO, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
     (void)hipFuncSetAttribute((const void*)f_backward_coop<HH, CC, EE, NO, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
     (void)hipFuncSetAttribute((const void*)f_backward_coop<HH, CC, EE, NO, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
+    set_pipe_lds<HH, CC, EE, NO>(lds_b);                                                                                        \
     (void)hipFuncSetAttribute((const void*)f_backward_coop<HH, CC, EE, NO, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
     (void)hipFuncSetAttribute((const void*)f_backward_coop<HH, CC, EE, NO, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
     (void)hipFuncSetAttribute((const void*)f_backward_coop<HH, CC, EE, NO, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
@@ -1942,6 +1976,16 @@ int gpe_debug_read_stamps(gpe_engine* e, unsigned long long out[16]) {
     HIPCHK(e, hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z));
     return GPE_OK;
 }
+
+#ifdef GPE_STAMP
+// tuning builds only (not part of include/gpe_hip.h): the per-workgroup phase trace of f_backward_pipe
+extern "C" int gpe_debug_read_trace(gpe_engine* e, unsigned long long* out, int n) {
+    if (!e || !out || n > 512 * 4 * 32) return GPE_ERR_INVALID;
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), (size_t)n * sizeof(unsigned long long)));
+    return GPE_OK;
+}
+#endif
 
 int gpe_step_cost(const gpe_engine* e, double* flops_per_point, double* hbm_bytes_per_point) {
     if (!e) return GPE_ERR_INVALID;

@@ -37,6 +37,12 @@
 #ifndef GPE_COOP_PRIO
 #define GPE_COOP_PRIO 1      // s_setprio level of the product phases of f_backward_coop (H <= 64); 0 switches it off
 #endif
+#ifndef GPE_PIPE_G0REG
+#define GPE_PIPE_G0REG 0     // f_backward_pipe: layer-0 gradient sums per lane in registers (1) or reduced per tile (0: 12 registers fewer)
+#endif
+#ifndef GPE_PIPE_PREFETCH
+#define GPE_PIPE_PREFETCH 1  // ... the next tile's top-layer stored jets requested one product phase ahead
+#endif
 #ifndef GPE_COOP_PRIO_P
 #define GPE_COOP_PRIO_P 0    // ... and of its VALU / LDS phases
 #endif
@@ -401,8 +407,17 @@ GPE_DEV unsigned long long stamp_now() {
     return t;
 }
 #define STAMP(i) do { unsigned long long _t = stamp_now(); st_acc[i] += _t - st_last; st_last = _t; } while (0)
+// f_backward_pipe: phase sums per wave (g_stamps[4 w + phase]: 0 barrier wait, 1 products, 2 VALU / LDS part) and, for every
+// workgroup, the stamps of tile iterations PT_IT0, PT_IT0 + 1 (g_trace[block][wave][0] = HW_ID, [1 + 12 it + 4 k + e]: interval k,
+// event e = 0 at the barrier, 1 behind it, 2 behind the products, 3 behind the VALU part)
+#define PT_IT0 40
+__device__ unsigned long long g_trace[512 * 4 * 32];
+#define PSTAMP(ph, ev) do { unsigned long long _t = stamp_now(); if ((ph) >= 0) st_acc[(ph) >= 0 ? (ph) : 0] += _t - st_last; st_last = _t; \
+        if (lane == 0 && vb < 512 && (it == PT_IT0 || it == PT_IT0 + 1))                                                       \
+            g_trace[(vb * 4 + w) * 32 + 1 + 12 * (it - PT_IT0) + (ev)] = _t; } while (0)
 #else
 #define STAMP(i) do { } while (0)
+#define PSTAMP(ph, ev) do { } while (0)
 #endif
 
 // Reverse pass.  Ob = dLoss/dO ([C][NOUT][ld]).  gslab: [gridDim.x][Ppad] per-workgroup gradient slabs.
@@ -1187,6 +1202,8 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_pipe(NetDesc nd, const fl
     constexpr int ZSZ = C * NT * 256;                // floats per exchange buffer (z fragments and X^T tiles alike: F_TILE = 256)
     static_assert(H <= 64 && F_TILE == 256, "register-resident weights; 16 x 16 exchange tiles");
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tix = threadIdx.x;
+    const int64_t vb = blockIdx.x, nvb = gridDim.x;
     // LDS: gsm (small-parameter gradients) | g0[4][H] | w0s small operands | ZB[2][C][NT][256] | XT[2][C][NT][256]
     const int n_gsm = (L - 1 + NOUT) * H + 4;        // b_1..b_{L-1} | W_out[NOUT][H] | b_out
     float* gsm = lds;
@@ -1194,7 +1211,7 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_pipe(NetDesc nd, const fl
     float* w0s = g0 + 4 * H;
     float* ZB = w0s + ((small_count(nd, H) + 3) & ~3);
     float* XT = ZB + 2 * ZSZ;
-    const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4, w = __builtin_amdgcn_readfirstlane(tix >> 6);
     const int dim = nd.dim;
     const float shift = nd.shift;
     const int64_t ntiles = (N + 15) >> 4;
@@ -1205,8 +1222,10 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_pipe(NetDesc nd, const fl
 #pragma unroll
     for (int s2 = 0; s2 < 4; ++s2) ztr[s2] = 4 * (((4 * q + s2) ^ (m >> 2)) + 16 * (m >> 2)) + (m & 3);
 
-    for (int i = threadIdx.x; i < ((n_gsm + 3) & ~3) + 4 * H; i += NTHR) gsm[i] = 0.f;      // gsm and g0 are contiguous
-    stage_layer0<H>(w0s, theta, nd, NTHR);
+    for (int i = tix; i < ((n_gsm + 3) & ~3) + 4 * H; i += NTHR) gsm[i] = 0.f;      // gsm and g0 are contiguous
+    // exchange buffers start as zeros: the first interval's deferred product (no tile before it) then adds nothing -- no special case
+    for (int i = tix; i < 4 * ZSZ / 4; i += NTHR) reinterpret_cast<f32x4*>(ZB)[i] = (f32x4)(0.f);
+    stage_layer0<H>(w0s, theta, nd, NTHR, tix);
     f32x4 wreg[NHH][NT];                               // K-slices of W_j^T: A operands of abar[16w..] = sum_nt W_j^T[16w.., 16nt..] z[16nt..]
 #pragma unroll
     for (int a = 0; a < NHH; ++a)
@@ -1220,6 +1239,8 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_pipe(NetDesc nd, const fl
         for (int kt = 0; kt < NT; ++kt) dwacc[a][kt] = (f32x4)(0.f);
     // small-parameter gradients of this wave's slice: per-lane sums over all tiles (see f_backward_coop), or per-tile reductions
     constexpr bool SREG = (C * NHH <= 12);
+    constexpr bool PREF = GPE_PIPE_PREFETCH && NOUT == 1;   // (complex psi: twice the output-jet adjoints in flight would spill)
+    constexpr bool G0REG = SREG && GPE_PIPE_G0REG;       // layer-0 sums per lane too (12 more registers in 2D)
     f32x4 dbacc[NHH], g0acc[4], gwoacc[NOUT];
     float gboacc[NOUT];
 #pragma unroll
@@ -1228,6 +1249,10 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_pipe(NetDesc nd, const fl
     for (int k = 0; k < 4; ++k) g0acc[k] = (f32x4)(0.f);
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) { gwoacc[o] = (f32x4)(0.f); gboacc[o] = 0.f; }
+    // the weight fragments have landed before the tile loop is entered, and the compiler knows it: else its wait-count bookkeeping
+    // (loop-entry state merged with the back edge) puts vmcnt waits in front of the first product phase of every tile, where
+    // they stall the matrix instructions on the stored-activation loads that were only just requested
+    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
     __syncthreads();
 
     // ---- pieces of a tile's work ---------------------------------------------------------------------------------------------
@@ -1301,30 +1326,12 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_pipe(NetDesc nd, const fl
             row_reduce4_add(v, &gsm[a * H + 16 * w], m, q);
         }
     };
-    // dW[rows of this slice][all columns] += Z^T X : NT independent accumulator chains.  zo: the z buffer that holds this map's z
-    // (own slice read feature-on-lane), xr: the X^T tiles of its input layer
-    auto wgrad_products = [&](f32x4 (&dw)[NT], const float* zo, const float* xr) {
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            f32x4 zt;
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) zt[s2] = zo[(c * NT + w) * 256 + ztr[s2]];
-            f32x4 xf[NT];
-#pragma unroll
-            for (int kt = 0; kt < NT; ++kt) xf[kt] = *reinterpret_cast<const f32x4*>(&xr[(c * NT + kt) * 256 + tr_roff(m, q)]);
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2)
-#pragma unroll
-                for (int kt = 0; kt < NT; ++kt) dw[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(zt[s2], xf[kt][s2], dw[kt], 0, 0, 0);
-        }
-    };
-
     // ---- first tile: output map, z of the top hidden layer into buffer 0 ------------------------------------------------------------
-    int64_t tile = blockIdx.x;
+    int64_t tile = vb;
+    const int64_t tend = ntiles;
     int par = 0;                                       // exchange buffers the next product phase READS
     f32x4 st[C];                                       // stored jets in flight for the next activation adjoint
-    bool have_pend = false;                            // map 1 of the previous tile waits for its dW product
-    if (tile < ntiles) {
+    if (tile < tend) {
         load_point(tile);
         f32x4 stl[C], zb[C];
         if constexpr (L - 1 >= 1) load_st(tile, L - 1, stl); else layer0_st<H, C, E>(w0s, xv, w, q, stl);
@@ -1333,9 +1340,25 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_pipe(NetDesc nd, const fl
         publish_z(zb, ZB);
         if constexpr (NHH - 1 >= 1) load_st(tile, NHH - 1, st);
     }
-    for (; tile < ntiles; tile += gridDim.x) {
-        const bool have_next = tile + gridDim.x < ntiles;
+#ifdef GPE_STAMP
+    unsigned long long st_acc[3] = {0, 0, 0};
+    unsigned long long st_last = stamp_now();
+    int it = -1;
+    if (lane == 0 && vb < 512) {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_trace[(vb * 4 + w) * 32] = ((unsigned long long)xcc << 32) | hwid;
+        g_trace[(vb * 4 + w) * 32 + 25] = st_last;       // tile loop entered
+    }
+#endif
+    for (; tile < tend; tile += nvb) {
+        const bool have_next = tile + nvb < tend;
         float xv_t[3] = {xv[0], xv[1], xv[2]};         // this tile's coordinates (layer 0 recompute, layer-0 gradients)
+#ifdef GPE_STAMP
+        ++it;
+#endif
 #pragma unroll
         for (int j = NHH; j >= 1; --j) {
             const float* zr = ZB + par * ZSZ;          // read side (filled in the previous interval)
@@ -1343,10 +1366,12 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_pipe(NetDesc nd, const fl
             float* zw = ZB + (par ^ 1) * ZSZ;          // write side; its z tiles are two intervals old until this interval's publish
             float* xw = XT + (par ^ 1) * ZSZ;
             f32x4 stn[C];                              // next tile's top-layer stored jets (requested in the tile's last interval)
+            PSTAMP(2, 4 * (NHH - j) + 0);
             __syncthreads();
-            if (j == 1 && have_next) {
-                load_point(tile + gridDim.x);
-                if constexpr (L - 1 >= 1) load_st(tile + gridDim.x, L - 1, stn);
+            PSTAMP(0, 4 * (NHH - j) + 1);
+            if (j == 1 && have_next && PREF) {
+                load_point(tile + nvb);
+                if constexpr (L - 1 >= 1) load_st(tile + nvb, L - 1, stn);
             }
             __builtin_amdgcn_s_setprio(GPE_COOP_PRIO);
             // abar (own slice) = sum_nt W_j^T[slice, nt] z[nt] : C independent accumulator chains
@@ -1364,10 +1389,27 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_pipe(NetDesc nd, const fl
                     for (int c = 0; c < C; ++c)
                         acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j - 1][nt][s2], bf[c][s2], acc[c], 0, 0, 0);
             }
-            // deferred weight-gradient product: map j+1 of this tile, or map 1 of the previous tile
-            if (j == NHH) { if (have_pend) wgrad_products(dwacc[0], zw, xr); }
-            else wgrad_products(dwacc[j < NHH ? j : 0], zw, xr);
+            // deferred weight-gradient product, dW[rows of this slice][all columns] += Z^T X with NT independent accumulator chains: map
+            // j+1 of this tile, or map 1 of the previous tile (the very first interval multiplies the zeros the buffers start with).
+            // Z^T: own slice of the write-side z buffer, two intervals old, read feature-on-lane
+            {
+                f32x4 (&dw)[NT] = dwacc[j < NHH ? j : 0];
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    f32x4 zt;
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2) zt[s2] = zw[(c * NT + w) * 256 + ztr[s2]];
+                    f32x4 xf[NT];
+#pragma unroll
+                    for (int kt = 0; kt < NT; ++kt) xf[kt] = *reinterpret_cast<const f32x4*>(&xr[(c * NT + kt) * 256 + tr_roff(m, q)]);
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                        for (int kt = 0; kt < NT; ++kt) dw[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(zt[s2], xf[kt][s2], dw[kt], 0, 0, 0);
+                }
+            }
             __builtin_amdgcn_s_setprio(GPE_COOP_PRIO_P);
+            PSTAMP(1, 4 * (NHH - j) + 2);
             // recompute X of layer j-1 (own slice), activation adjoint -> z of layer j-1, X^T into the write-side buffer
             f32x4 sj[C];
             if (j - 1 >= 1) {
@@ -1387,7 +1429,7 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_pipe(NetDesc nd, const fl
                 if (j - 2 >= 1) load_st(tile, j - 2, st);
             } else {
                 // ---- linear map 0, own slice: g0[k][n] (k < dim: dW0[n][k]; k = 3: db0[n]) ----------------------------------------
-                if constexpr (SREG) g0acc[3] += zb[0];
+                if constexpr (G0REG) g0acc[3] += zb[0];
                 else {
                     const float z0[4] = {zb[0][0], zb[0][1], zb[0][2], zb[0][3]};
                     row_reduce4_add(z0, &g0[3 * H + 16 * w], m, q);
@@ -1397,63 +1439,94 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_pipe(NetDesc nd, const fl
                     if (k < D || (D == 0 && k < dim)) {
                         f32x4 v = zb[0] * xv_t[k];
                         if constexpr (C > 1) { if (k < D) v += zb[(1 + k) < C ? (1 + k) : 0]; }
-                        if constexpr (SREG) g0acc[k] += v;
+                        if constexpr (G0REG) g0acc[k] += v;
                         else {
                             const float vv[4] = {v[0], v[1], v[2], v[3]};
                             row_reduce4_add(vv, &g0[k * H + 16 * w], m, q);
                         }
                     }
                 }
-                have_pend = true;                      // map 1's X^T is on the write side: its product runs behind the next barrier
+                // (map 1's X^T is on the write side: its dW product runs behind the next barrier)
                 // ---- next tile: output map, z of its top hidden layer --------------------------------------------------------------
                 if (have_next) {
+                    if (!PREF) {
+                        load_point(tile + nvb);
+                        if constexpr (L - 1 >= 1) load_st(tile + nvb, L - 1, stn);
+                    }
                     f32x4 zn[C];
                     if constexpr (L - 1 >= 1) output_stage(stn, zn);
                     else { f32x4 s0[C]; layer0_st<H, C, E>(w0s, xv, w, q, s0); output_stage(s0, zn); }
                     bias_sum(zn[0], NHH - 1);
                     publish_z(zn, zw);
-                    if constexpr (NHH - 1 >= 1) load_st(tile + gridDim.x, NHH - 1, st);
+                    if constexpr (NHH - 1 >= 1) load_st(tile + nvb, NHH - 1, st);
                 }
             }
             par ^= 1;
         }
     }
+#ifdef GPE_STAMP
+    if (lane == 0) for (int i = 0; i < 3; ++i) atomicAdd(&g_stamps[4 * w + i], st_acc[i]);
+    if (lane == 0 && vb < 512) g_trace[(vb * 4 + w) * 32 + 26] = stamp_now();      // tile loop left
+#endif
     // ---- the last tile's deferred dW_1 product ----------------------------------------------------------------------------------
     __syncthreads();
-    if (have_pend) wgrad_products(dwacc[0], ZB + (par ^ 1) * ZSZ, XT + par * ZSZ);
+    // the epilogue's lane arithmetic starts from an opaque copy: hoisted above the tile loop it would sit in registers (or scratch) all along
+    int le = lane;
+    asm volatile("" : "+v"(le));
+    const int me = le & 15, qe = le >> 4;
+    {
+        const float* zo = ZB + (par ^ 1) * ZSZ;
+        const float* xr = XT + par * ZSZ;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            f32x4 zt;
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) zt[s2] = zo[(c * NT + w) * 256 + 4 * (((4 * qe + s2) ^ (me >> 2)) + 16 * (me >> 2)) + (me & 3)];
+            f32x4 xf[NT];
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) xf[kt] = *reinterpret_cast<const f32x4*>(&xr[(c * NT + kt) * 256 + tr_roff(me, qe)]);
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt)
+                    dwacc[0][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(zt[s2], xf[kt][s2], dwacc[0][kt], 0, 0, 0);
+        }
+    }
     // ---- the per-lane sums: across the 16 point lanes, into the workgroup's LDS block (zeroed above; every wave owns its rows) --------
     if constexpr (SREG) {
         auto reduce4 = [&](const f32x4& a, float* dst16) {
             const float v[4] = {a[0], a[1], a[2], a[3]};
-            row_reduce4_add(v, dst16, m, q);
+            row_reduce4_add(v, dst16, me, qe);
         };
 #pragma unroll
         for (int a = 0; a < NHH; ++a) reduce4(dbacc[a], &gsm[a * H + 16 * w]);
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) reduce4(gwoacc[o], &gsm[(L - 1 + o) * H + 16 * w]);
+        if constexpr (G0REG) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) reduce4(g0acc[k], &g0[k * H + 16 * w]);
+            for (int k = 0; k < 4; ++k) reduce4(g0acc[k], &g0[k * H + 16 * w]);
+        }
         if (w == 0) {
 #pragma unroll
             for (int o = 0; o < NOUT; ++o) {
                 const float gbo = row_sum16(gboacc[o]);
-                if (lane == 0) atomicAdd(&gsm[(L - 1 + NOUT) * H + o], gbo);
+                if (le == 0) atomicAdd(&gsm[(L - 1 + NOUT) * H + o], gbo);
             }
         }
     }
     // ---- slab: H x H rows from the accumulators, the rest from LDS ---------------------------------------------------------
-    float* slab = gslab + (size_t)blockIdx.x * Ppad;
+    float* slab = gslab + (size_t)vb * Ppad;
 #pragma unroll
     for (int a = 0; a < NHH; ++a)
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) slab[nd.offW[a + 1] + (16 * w + 4 * q + r) * H + 16 * kt + m] = dwacc[a][kt][r];
+            for (int r = 0; r < 4; ++r) slab[nd.offW[a + 1] + (16 * w + 4 * qe + r) * H + 16 * kt + me] = dwacc[a][kt][r];
     __syncthreads();
-    for (int i = threadIdx.x; i < (L - 1) * H; i += NTHR) slab[nd.offB[1 + i / H] + i % H] = gsm[i];
-    for (int i = threadIdx.x; i < NOUT * H; i += NTHR) slab[nd.offW[L] + i] = gsm[(L - 1) * H + i];
-    for (int i = threadIdx.x; i < NOUT; i += NTHR) slab[nd.offB[L] + i] = gsm[(L - 1 + NOUT) * H + i];
-    for (int i = threadIdx.x; i < 4 * H; i += NTHR) {
+    for (int i = tix; i < (L - 1) * H; i += NTHR) slab[nd.offB[1 + i / H] + i % H] = gsm[i];
+    for (int i = tix; i < NOUT * H; i += NTHR) slab[nd.offW[L] + i] = gsm[(L - 1) * H + i];
+    for (int i = tix; i < NOUT; i += NTHR) slab[nd.offB[L] + i] = gsm[(L - 1 + NOUT) * H + i];
+    for (int i = tix; i < 4 * H; i += NTHR) {
         const int n = i % H, k = i / H;
         if (k == 3) slab[nd.offB[0] + n] = g0[i];
         else if (k < dim) slab[nd.offW[0] + n * dim + k] = g0[i];

@@ -112,18 +112,19 @@ GPE_DEV void tiles_transpose(const f32x4 (&v)[C], f32x4 (&o)[C], float* T, int m
 // output bias -- every small operand the per-tile code reads, so that no global (L2-latency) load sits inside a tile.
 GPE_DEV int small_count(const NetDesc& nd, int H) { return (4 + (nd.n_lin - 2) + nd.n_out) * H + 4; }
 template <int H>
-GPE_DEV void stage_layer0(float* w0s, const float* __restrict__ theta, const NetDesc& nd, int nthr) {
+GPE_DEV void stage_layer0(float* w0s, const float* __restrict__ theta, const NetDesc& nd, int nthr, int tix = -1) {
     const int L = nd.n_lin - 1;
-    for (int i = threadIdx.x; i < 4 * H; i += nthr) {
+    if (tix < 0) tix = threadIdx.x;               // (tix: thread index within the group of nthr threads that fills this copy)
+    for (int i = tix; i < 4 * H; i += nthr) {
         const int k = i / H, n = i % H;
         float v;
         if (k == 3) v = theta[nd.offB[0] + n];
         else v = (k < nd.dim) ? theta[nd.offW[0] + n * nd.dim + k] : 0.f;
         w0s[i] = v;
     }
-    for (int i = threadIdx.x; i < (L - 1) * H; i += nthr) w0s[4 * H + i] = theta[nd.offB[1 + i / H] + i % H];
-    for (int i = threadIdx.x; i < nd.n_out * H; i += nthr) w0s[(4 + L - 1) * H + i] = theta[nd.offW[L] + i];
-    for (int i = threadIdx.x; i < nd.n_out; i += nthr) w0s[(4 + L - 1 + nd.n_out) * H + i] = theta[nd.offB[L] + i];
+    for (int i = tix; i < (L - 1) * H; i += nthr) w0s[4 * H + i] = theta[nd.offB[1 + i / H] + i % H];
+    for (int i = tix; i < nd.n_out * H; i += nthr) w0s[(4 + L - 1) * H + i] = theta[nd.offW[L] + i];
+    for (int i = tix; i < nd.n_out; i += nthr) w0s[(4 + L - 1 + nd.n_out) * H + i] = theta[nd.offB[L] + i];
 }
 
 // stored-equivalent (t, z_k, z_kk) of hidden layer 0 for features 16nt+4q+r, recomputed from the point coordinates
