@@ -13,6 +13,6 @@ from ._capi import (ACT_TANH, ACT_TANH_PLUS1, POT_GAUSSIAN, POT_HARMONIC, POT_NO
                     SCHED_CONST, SCHED_COSINE_LOSS, SCHED_PLATEAU, PATH_AUTO, PATH_GENERIC, PATH_FUSED)
 from .engine import Engine, GPEConfig, GPEError
 from . import dp, surface, checkpoint, relobralo
-from .surface import refine, notebook, box, gravity_well, box_to_gaussian
+from .surface import refine, refine_negative, notebook, box, gravity_well, box_to_gaussian
 
-__all__ = ["capi", "Engine", "GPEConfig", "GPEError", "dp", "surface", "checkpoint", "refine", "notebook", "box", "gravity_well", "box_to_gaussian"]
+__all__ = ["capi", "Engine", "GPEConfig", "GPEError", "dp", "surface", "checkpoint", "refine", "refine_negative", "notebook", "box", "gravity_well", "box_to_gaussian"]

@@ -18,7 +18,15 @@
 #include <string>
 #include <vector>
 
-#include <rccl/rccl.h>      // types only: the library is dlopen'ed at gpe_comm_init (no link-time dependency)
+// RCCL is dlopen'ed at gpe_comm_init: no link-time dependency, and no build-time one either -- the handful of types and enum
+// values the five entry points need are declared here as rccl.h (NCCL 2.x ABI) declares them.
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+typedef enum { ncclFloat = 7, ncclDouble = 8 } ncclDataType_t;
+}
 
 #include "gpe_common.h"
 #include "gpe_head.h"
@@ -53,21 +61,23 @@ static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1
 // ------------------------------------------------------------------------------------------------
 // update kernel: clip_grad_norm_ + Adam + scheduler + record   (refine/...:359-361, 364-381)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_update(int P, float* __restrict__ theta, float* __restrict__ am,
-                                                  float* __restrict__ av, const float* __restrict__ grad,
-                                                  const double* __restrict__ sums, const double* __restrict__ lsums,
-                                                  Phys ph, OptCfg oc, OptDev* __restrict__ od,
-                                                  gpe_scalars* __restrict__ hist, int cap, gpe_scalars* __restrict__ last,
-                                                  double bc_cnt, int do_update, int mse_mode, NetDesc nd, int H,
-                                                  float* __restrict__ Wpk, float* __restrict__ WpkT, int n_pack,
-                                                  double* __restrict__ dbl, int n_dbl, double* __restrict__ dbl_keep) {
+// Large parameter vectors (P >= UPD_MULTI_MIN: [2,128x5,1] and up) run the update on UPD_G workgroups -- one workgroup took 0.40 ms
+// per step at P = 330 241.  k_update_part: per-workgroup partial sums of |g|^2 over contiguous chunks (fixed order: deterministic
+// for a given P) + a snapshot of the step sums and of the optimiser state; k_update<true>: every workgroup adds the partial sums in the
+// same order and derives the same clip factor / step size from the SNAPSHOTS (workgroup 0 alone writes the optimiser state, the
+// record and the history, and zeroes the step sums), then updates its chunk.  The repacking of the hidden-hidden weights needs ALL
+// updated parameters, so it is left to the next step's k_begin in this mode.
+#define UPD_G 64
+#define UPD_MULTI_MIN 32768
+struct UpdSnap { double sums[S_COUNT]; double lsums[LS_COUNT]; OptDev od; double part[UPD_G]; };
+GPE_DEV int upd_chunk(int P) { return (((P + UPD_G - 1) / UPD_G) + 3) & ~3; }
+__global__ __launch_bounds__(1024) void k_update_part(int P, const float* __restrict__ grad, const double* __restrict__ sums,
+                                                       const double* __restrict__ lsums, const OptDev* __restrict__ od,
+                                                       UpdSnap* __restrict__ snap) {
     __shared__ double red[16];
-    __shared__ float s_coef, s_ss, s_b2s;
-    __shared__ int s_skip, s_book, s_frozen;
-    __shared__ long long s_step;
-    __shared__ gpe_scalars s_rec;
+    const int chunk = upd_chunk(P), lo = blockIdx.x * chunk, hi = min(P, lo + chunk);
     double acc = 0.0;
-    for (int i = threadIdx.x; i < P; i += 1024) { double g = grad[i]; acc += g * g; }
+    for (int i = lo + threadIdx.x; i < hi; i += 1024) { double g = grad[i]; acc += g * g; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -75,6 +85,47 @@ __global__ __launch_bounds__(1024) void k_update(int P, float* __restrict__ thet
     if (threadIdx.x == 0) {
         double tot = 0.0;
         for (int i = 0; i < 16; ++i) tot += red[i];
+        snap->part[blockIdx.x] = tot;
+    }
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < S_COUNT) snap->sums[threadIdx.x] = sums[threadIdx.x];
+        if (threadIdx.x < LS_COUNT) snap->lsums[threadIdx.x] = lsums[threadIdx.x];
+        if (threadIdx.x == 64) snap->od = *od;
+    }
+}
+
+template <bool MULTI>
+__global__ __launch_bounds__(1024) void k_update(int P, float* __restrict__ theta, float* __restrict__ am,
+                                                  float* __restrict__ av, const float* __restrict__ grad,
+                                                  const double* __restrict__ sums_in, const double* __restrict__ lsums_in,
+                                                  Phys ph, OptCfg oc, OptDev* __restrict__ od,
+                                                  gpe_scalars* __restrict__ hist, int cap, gpe_scalars* __restrict__ last,
+                                                  double bc_cnt, int do_update, int mse_mode, NetDesc nd, int H,
+                                                  float* __restrict__ Wpk, float* __restrict__ WpkT, int n_pack,
+                                                  double* __restrict__ dbl, int n_dbl, double* __restrict__ dbl_keep,
+                                                  const UpdSnap* __restrict__ snap) {
+    __shared__ double red[16];
+    __shared__ float s_coef, s_ss, s_b2s;
+    __shared__ int s_skip, s_book, s_frozen;
+    __shared__ long long s_step;
+    __shared__ gpe_scalars s_rec;
+    const double* sums = MULTI ? snap->sums : sums_in;
+    const double* lsums = MULTI ? snap->lsums : lsums_in;
+    const OptDev* odr = MULTI ? &snap->od : od;                    // state the step size is derived from
+    const bool lead = !MULTI || blockIdx.x == 0;                   // the workgroup that writes the optimiser state / record / history
+    const int lo = MULTI ? blockIdx.x * upd_chunk(P) : 0, hi = MULTI ? min(P, lo + upd_chunk(P)) : P;
+    if constexpr (!MULTI) {
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < P; i += 1024) { double g = grad[i]; acc += g * g; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        if constexpr (MULTI) { for (int i = 0; i < UPD_G; ++i) tot += snap->part[i]; }
+        else { for (int i = 0; i < 16; ++i) tot += red[i]; }
         double gn = sqrt(tot);
         double num = sums[S_NUM], den = sums[S_DEN];
         double lam = (double)(float)(num / den);
@@ -97,14 +148,14 @@ __global__ __launch_bounds__(1024) void k_update(int P, float* __restrict__ thet
             lam = 0.0; pde = 0.0; nrm = 0.0; bc = 0.0; sym = 0.0; orth = 0.0; riesz = 0.0;
         }
         int skip = !(isfinite(loss) && isfinite(gn));
-        const int frozen = do_update && od->stopped;
-        long long step = od->step + (do_update && !skip && !frozen ? 1 : 0);
-        double lr = od->lr;
+        const int frozen = do_update && odr->stopped;
+        long long step = odr->step + (do_update && !skip && !frozen ? 1 : 0);
+        double lr = odr->lr;
         float coef = 1.0f;
         if (oc.clip_norm > 0.f && !mse_mode) coef = (float)fmin(1.0, (double)oc.clip_norm / (gn + 1e-6));
         const bool commit = do_update && !skip && !frozen;
-        const double b1p = commit ? od->b1p * (double)oc.beta1 : od->b1p, b2p = commit ? od->b2p * (double)oc.beta2 : od->b2p;
-        if (commit) { od->b1p = b1p; od->b2p = b2p; }
+        const double b1p = commit ? odr->b1p * (double)oc.beta1 : odr->b1p, b2p = commit ? odr->b2p * (double)oc.beta2 : odr->b2p;
+        if (commit && lead) { od->b1p = b1p; od->b2p = b2p; }
         double bc1 = 1.0 - b1p;
         double bc2 = 1.0 - b2p;
         s_coef = coef;
@@ -120,7 +171,7 @@ __global__ __launch_bounds__(1024) void k_update(int P, float* __restrict__ thet
     __syncthreads();
     // bookkeeping (record, history, early stop, scheduler: double-precision log / pow / cos) on the last thread, concurrently
     // with the Adam loop of the others
-    if (threadIdx.x == 1023 && s_book) {
+    if (threadIdx.x == 1023 && s_book && lead) {
         const gpe_scalars r = s_rec;
         const long long step = s_step;
         const int frozen = s_frozen, skip = r.nonfinite != 0.0;
@@ -166,7 +217,7 @@ __global__ __launch_bounds__(1024) void k_update(int P, float* __restrict__ thet
     if (!s_skip) {
         const float coef = s_coef, ss = s_ss, b2s = s_b2s;
         const float b1 = oc.beta1, b2 = oc.beta2, eps = oc.eps;
-        for (int i = threadIdx.x; i < P; i += 1024) {
+        for (int i = lo + threadIdx.x; i < hi; i += 1024) {
             float g = grad[i] * coef;
             float m = am[i], v = av[i];
             m = m + (g - m) * (1.0f - b1);                 // exp_avg.lerp_(grad, 1-beta1)
@@ -180,8 +231,8 @@ __global__ __launch_bounds__(1024) void k_update(int P, float* __restrict__ thet
     // before the barrier above) -> zero them; repack the hidden-hidden weights in MFMA fragment order from the new parameters.
     __syncthreads();
     // (stale-gradient mode: this step's sums are kept for the NEXT update, which applies this step's gradient)
-    for (int i = threadIdx.x; i < n_dbl; i += 1024) { if (dbl_keep) dbl_keep[i] = dbl[i]; dbl[i] = 0.0; }
-    for (int i = threadIdx.x; i < n_pack; i += 1024) pack_weight_element(nd, H, theta, Wpk, WpkT, i);
+    if (lead) for (int i = threadIdx.x; i < n_dbl; i += 1024) { if (dbl_keep) dbl_keep[i] = dbl[i]; dbl[i] = 0.0; }
+    if constexpr (!MULTI) for (int i = threadIdx.x; i < n_pack; i += 1024) pack_weight_element(nd, H, theta, Wpk, WpkT, i);
 }
 
 // closes the reverse phase: adds the boundary-batch gradient (computed on the side stream) and fills the exchange tail
@@ -229,6 +280,7 @@ struct gpe_engine {
     float *theta = nullptr, *am = nullptr, *av = nullptr, *grad = nullptr;   // grad: P + GT_COUNT
     double* dbl = nullptr;         // [S_COUNT sums | LS_COUNT local | 4 misc]
     OptDev* od = nullptr;
+    UpdSnap* upd_snap = nullptr;   // multi-workgroup update (P >= UPD_MULTI_MIN): partial norms + snapshot of sums / optimiser state
     gpe_scalars *hist = nullptr, *last = nullptr;
     int cap = 65536;
     float *Wpk = nullptr, *WpkT = nullptr, *gslab = nullptr;
@@ -1075,6 +1127,10 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
               alloc((void**)&e->dbl, (S_COUNT + LS_COUNT + 4) * sizeof(double)) && alloc((void**)&e->od, sizeof(OptDev)) &&
               alloc((void**)&e->hist, (size_t)e->cap * sizeof(gpe_scalars)) && alloc((void**)&e->last, sizeof(gpe_scalars)) &&
               alloc((void**)&e->orth_dev, 8 * sizeof(float*));
+    {
+        const char* envu = getenv("GPE_UPDATE_MULTI");               // 0: the single-workgroup update at every size
+        if (ok && e->P >= UPD_MULTI_MIN && !(envu && atoi(envu) == 0)) ok = alloc((void**)&e->upd_snap, sizeof(UpdSnap));
+    }
     if (ok && e->path == GPE_PATH_FUSED) {
         e->nslab = (H >= 128) ? std::max(e->nslab_g, e->num_cu) : e->num_cu * 2;     // H = 128: 16 atomic slabs, or one per workgroup (cooperative)
         if (e->wide) wide_init();
@@ -1208,7 +1264,7 @@ void gpe_destroy(gpe_engine* e) {
     free_batch(e->main); free_batch(e->bc); free_batch(e->sym); free_batch(e->aux); free_batch(e->mse);
     for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
     if (e->ext_exchange) { e->grad = nullptr; e->dbl = nullptr; }
-    void* ps[] = {e->theta, e->am, e->av, e->grad, e->dbl, e->od, e->hist, e->last, (void*)e->orth_dev, e->Wpk, e->WpkT, e->gslab, e->gslab_bc, e->grad_bc};
+    void* ps[] = {e->theta, e->am, e->av, e->grad, e->dbl, e->od, e->hist, e->last, (void*)e->orth_dev, e->Wpk, e->WpkT, e->gslab, e->gslab_bc, e->grad_bc, (void*)e->upd_snap};
     for (void* p : ps) if (p) (void)hipFree(p);
     delete e;
 }
@@ -1501,12 +1557,23 @@ int gpe_step_backward(gpe_engine* e) {
     return GPE_OK;
 }
 
-// trailing arguments of k_update: what it needs to prepare the next step (weight packing on the fused path, sum zeroing)
-#define UPD_TAIL_ARGS e->nd, e->H, e->Wpk, e->WpkT, (e->path == GPE_PATH_FUSED ? (e->nd.n_lin - 2) * e->H * e->H : 0), e->dbl, \
-                      (int)(S_COUNT + LS_COUNT + 4), (double*)nullptr
 static void after_update(gpe_engine* e) {          // host-side mirror of what k_update left behind
     e->acc_clean = true;
-    e->packed_dirty = false;
+    e->packed_dirty = e->path == GPE_PATH_FUSED && e->upd_snap != nullptr;      // multi-workgroup update: the next k_begin repacks
+}
+static void launch_update(gpe_engine* e, const float* grad, const double* sums, const double* lsums, double bc_cnt, int do_update,
+                          int mse_mode, double* dbl_keep) {
+    const int n_pack = e->path == GPE_PATH_FUSED ? (e->nd.n_lin - 2) * e->H * e->H : 0;
+    if (e->upd_snap) {
+        hipLaunchKernelGGL(k_update_part, dim3(UPD_G), dim3(1024), 0, e->stream, e->P, grad, sums, lsums, e->od, e->upd_snap);
+        hipLaunchKernelGGL(k_update<true>, dim3(UPD_G), dim3(1024), 0, e->stream, e->P, e->theta, e->am, e->av, grad, sums, lsums, e->ph,
+                           e->oc, e->od, e->hist, e->cap, e->last, bc_cnt, do_update, mse_mode, e->nd, e->H, e->Wpk, e->WpkT, n_pack, e->dbl,
+                           (int)(S_COUNT + LS_COUNT + 4), dbl_keep, (const UpdSnap*)e->upd_snap);
+    } else {
+        hipLaunchKernelGGL(k_update<false>, dim3(1), dim3(1024), 0, e->stream, e->P, e->theta, e->am, e->av, grad, sums, lsums, e->ph,
+                           e->oc, e->od, e->hist, e->cap, e->last, bc_cnt, do_update, mse_mode, e->nd, e->H, e->Wpk, e->WpkT, n_pack, e->dbl,
+                           (int)(S_COUNT + LS_COUNT + 4), dbl_keep, (const UpdSnap*)nullptr);
+    }
 }
 static double bc_count(gpe_engine* e) {
     const int64_t nb = e->nb_merged > 0 ? e->nb_merged : e->bc.n;
@@ -1516,8 +1583,7 @@ static double bc_count(gpe_engine* e) {
 int gpe_step_update(gpe_engine* e) {
     if (!e) return GPE_ERR_INVALID;
     if (e->phase != 2) FAIL(e, GPE_ERR_STATE, "step_update without step_backward");
-    hipLaunchKernelGGL(k_update, dim3(1), dim3(1024), 0, e->stream, e->P, e->theta, e->am, e->av, e->grad, e->sums(),
-                       e->lsums(), e->ph, e->oc, e->od, e->hist, e->cap, e->last, bc_count(e), 1, 0, UPD_TAIL_ARGS);
+    launch_update(e, e->grad, e->sums(), e->lsums(), bc_count(e), 1, 0, nullptr);
     HIPCHK(e, hipGetLastError());
     after_update(e);
     e->phase = 0;
@@ -1551,8 +1617,7 @@ int gpe_mse_begin(gpe_engine* e) {
 static int mse_finish(gpe_engine* e, int do_update) {
     if (e->phase != 3) FAIL(e, GPE_ERR_STATE, "mse update without mse begin");
     // sums[S_DEN] must be non-zero for the (unused) Rayleigh quotient of the shared update kernel
-    hipLaunchKernelGGL(k_update, dim3(1), dim3(1024), 0, e->stream, e->P, e->theta, e->am, e->av, e->grad, e->sums(),
-                       e->lsums(), e->ph, e->oc, e->od, e->hist, e->cap, e->last, 0.0, do_update, 1, UPD_TAIL_ARGS);
+    launch_update(e, e->grad, e->sums(), e->lsums(), 0.0, do_update, 1, nullptr);
     HIPCHK(e, hipGetLastError());
     after_update(e);
     e->phase = 0;
@@ -1714,11 +1779,8 @@ static int step_dp_async(gpe_engine* e) {
     float* gprev = (prv == 1) ? e->grad_alt : e->grad;
     const int apply = e->async_t > 0;
     HIPCHK(e, hipStreamWaitEvent(e->stream, e->ev_g[apply ? prv : cur], 0));     // step 0 only records: it reads its own (reduced) tail
-    hipLaunchKernelGGL(k_update, dim3(1), dim3(1024), 0, e->stream, e->P, e->theta, e->am, e->av, apply ? gprev : gcur,
-                       apply ? (const double*)e->dbl_prev : (const double*)e->sums(),
-                       apply ? (const double*)(e->dbl_prev + S_COUNT) : (const double*)e->lsums(), e->ph, e->oc, e->od, e->hist, e->cap,
-                       e->last, bc_count(e), apply, 0, e->nd, e->H, e->Wpk, e->WpkT,
-                       (e->path == GPE_PATH_FUSED ? (e->nd.n_lin - 2) * e->H * e->H : 0), e->dbl, (int)(S_COUNT + LS_COUNT + 4), e->dbl_prev);
+    launch_update(e, apply ? gprev : gcur, apply ? (const double*)e->dbl_prev : (const double*)e->sums(),
+                  apply ? (const double*)(e->dbl_prev + S_COUNT) : (const double*)e->lsums(), bc_count(e), apply, 0, e->dbl_prev);
     HIPCHK(e, hipGetLastError());
     after_update(e);
     e->phase = 0;
@@ -1899,8 +1961,7 @@ int gpe_residual(gpe_engine* e, gpe_scalars* out, float* d_psi, float* d_resid) 
     if (d_psi) hipLaunchKernelGGL(k_copy_psi, dim3(cdiv(e->n_pde, 256)), dim3(256), 0, e->stream, e->main.u, d_psi, e->n_pde,
                                   e->main.ld, e->nd.n_out);
     if ((rc = launch_tail(e, false))) return rc;
-    hipLaunchKernelGGL(k_update, dim3(1), dim3(1024), 0, e->stream, e->P, e->theta, e->am, e->av, e->grad, e->sums(),
-                       e->lsums(), e->ph, e->oc, e->od, e->hist, e->cap, e->last, bc_count(e), 0, 0, UPD_TAIL_ARGS);
+    launch_update(e, e->grad, e->sums(), e->lsums(), bc_count(e), 0, 0, nullptr);
     HIPCHK(e, hipGetLastError());
     after_update(e);
     e->phase = 0;

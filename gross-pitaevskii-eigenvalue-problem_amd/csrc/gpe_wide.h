@@ -416,6 +416,7 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
                         f32x4 gg = (f32x4)(0.f);
 #pragma unroll
                         for (int c = 0; c < C; ++c) gg = gpe_fma((f32x4)(obv[o][c]), a4[c], gg);
+                        asm volatile("" : "+v"(gg));           // formed here, not sunk below the adjoint (a4 would stay live)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) gwo[o][r] = gg[r];
                     }

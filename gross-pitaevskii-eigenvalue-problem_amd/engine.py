@@ -183,9 +183,15 @@ class Engine:
         return dict(kv.split("=", 1) for kv in buf.value.decode().split(";"))
 
     # ---- data-parallel exchange inside the engine (RCCL on the engine's exchange stream) ---------------------------------
+    _comm_seq = 0          # communicators created by this process: every rank creates them in the same order
+
     def comm_init(self, rank: int, world: int, store=None, key: str = "gpe_comm_id"):
         """Create the engine's own RCCL communicator.  The 128-byte ncclUniqueId travels through `store` (anything with
-        set/get, e.g. the TCPStore of an initialised torch.distributed group, the default when none is given)."""
+        set/get, e.g. the TCPStore of an initialised torch.distributed group, the default when none is given) under a key that
+        is unique per communicator (`key`/<sequence number>): a second engine, or a communicator re-created after comm_destroy,
+        never reads the id of an earlier one."""
+        key = f"{key}/{Engine._comm_seq}"
+        Engine._comm_seq += 1
         if store is None and world > 1:
             import torch.distributed as dist
             store = dist.distributed_c10d._get_default_store()

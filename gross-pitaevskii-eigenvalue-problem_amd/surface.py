@@ -346,6 +346,9 @@ class _BoxToGaussianPINN(_RefinePINN):
     def __init__(self, layers, hbar=1.0, m=1.0, mode=0, gamma=1.0, L=1.0, use_residual=True):
         self.use_residual = bool(use_residual)
         self.L = L
+        # the reference constructor builds its network TWICE (refine/box_to_gaussian_pinn_simulation.py:90 and :98): two default-init
+        # draws from the global RNG before advanced_initialization -- consume the first one here so that seeded runs start alike
+        _default_init(list(layers), _residual_spec(list(layers)) if self.use_residual else None)
         super().__init__(layers, hbar, m, mode, gamma, True)
 
     def _spec(self):
@@ -513,7 +516,8 @@ def _refine_pretrain(model, mode, X_train, epochs=5000, lr=1e-3, verbose=False):
 
 
 def _refine_train(gamma_values, modes, p, X_train, lb, ub, layers, epochs, tol, perturb_const,
-                  potential_type="harmonic", lr=1e-5, verbose=True, pretrain="reference", chunk=500, _cls=None, **model_kw):
+                  potential_type="harmonic", lr=1e-5, verbose=True, pretrain="reference", chunk=500, _cls=None, _descending=False,
+                  **model_kw):
     """train_gpe_model of refine/harmonic_pinn_simulation.py:220-430 (PL-PINN, gamma continuation).
 
     Differences from the reference, all deliberate:
@@ -534,7 +538,7 @@ def _refine_train(gamma_values, modes, p, X_train, lb, ub, layers, epochs, tol, 
     X_dev = torch.as_tensor(X.astype(np.float32), device=dev)
     bpts = torch.tensor([[lb], [ub]], dtype=torch.float32, device=dev)
     models_by_mode, mu_table, training_history, constant_history, epochs_history = {}, {}, {}, {}, {}
-    gamma_values = sorted(gamma_values)
+    gamma_values = sorted(gamma_values, reverse=bool(_descending))
     if verbose:
         print(f"Tolerance : {tol}, Perturbation constant : {perturb_const}")
     for mode in modes:
@@ -729,6 +733,19 @@ gravity_well = types.SimpleNamespace(GrossPitaevskiiPINN=_GravityWellPINN, train
 box = types.SimpleNamespace(GrossPitaevskiiPINN=_BoxPINN, train_gpe_model=_box_train,
                             advanced_initialization=_refine_advanced_initialization,
                             pretrain_on_analytical_solution=_refine_pretrain)
+def _refine_negative_train(gamma_values, modes, p, X_train, lb, ub, layers, epochs, tol, perturb_const, potential_type="harmonic",
+                           lr=1e-5, verbose=True, **kw):
+    """train_gpe_model of refine/harmonic_pinn_simulation_negative_interaction_strength.py:217-428: the same residual and epoch body as
+    the main script, the continuation walks the (sorted) interaction strengths DOWNWARDS -- 0, -0.5, ... (:271, :286) -- so the
+    warm start and normal_const come from gamma = 0 although the attractive values sort first."""
+    return _refine_train(gamma_values, modes, p, X_train, lb, ub, layers, epochs, tol, perturb_const, potential_type, lr, verbose,
+                         _descending=True, **kw)
+
+
+refine_negative = types.SimpleNamespace(GrossPitaevskiiPINN=_RefinePINN, train_gpe_model=_refine_negative_train,
+                                        advanced_initialization=_refine_advanced_initialization,
+                                        pretrain_on_analytical_solution=_refine_pretrain,
+                                        normalized_wavefunction=_refine_wavefunction, KIND="xavier_normal")
 refine = types.SimpleNamespace(GrossPitaevskiiPINN=_RefinePINN, train_gpe_model=_refine_train,
                                advanced_initialization=_refine_advanced_initialization,
                                pretrain_on_analytical_solution=_refine_pretrain,

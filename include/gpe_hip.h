@@ -12,9 +12,10 @@
  *     (e.g. tensor.data_ptr() of a PyTorch-ROCm tensor used as storage); h_* are host pointers.
  *   - Every function returns GPE_OK (0) or a negative gpe_status; gpe_last_error() gives the text.
  *     No exception crosses the ABI.
- *   - A handle is single-device and not thread-safe.  One process per GPU; data-parallel exchange is
- *     done by the caller (RCCL through torch.distributed) on the two device buffers exposed by
- *     gpe_exchange_sums() / gpe_exchange_grad() between the three phases of a step.
+ *   - A handle is single-device and not thread-safe.  One process per GPU.  Data-parallel exchange: either
+ *     by the engine itself -- gpe_comm_unique_id / gpe_comm_init create an RCCL communicator and gpe_step_dp /
+ *     gpe_run_dp issue both all-reduces of a step on a dedicated stream -- or by the caller, on the two device
+ *     buffers exposed by gpe_exchange_sums() / gpe_exchange_grad() between the three phases of a step.
  *   - All kernels run on the stream given at gpe_create() (NULL = the legacy default stream).
  *   - Parameters are one flat fp32 vector in torch state_dict order:
  *       network.0.weight [out,in] row-major, network.0.bias, network.2.weight, ...

@@ -40,6 +40,15 @@ def problem_from_nb(fx) -> go.Problem:
                       dx=float(fx["dx"]))
 
 
+def problem_from_vanilla(fx) -> go.Problem:
+    """use_perturbation=False of refine/harmonic_pinn_simulation.py (:152-155, :205-208): the scaled network output IS u (no base) in the
+    residual and the norm; the boundary term takes the raw network output."""
+    return go.Problem(layers=[int(v) for v in fx["layers"]], activation=1, kinetic_coeff=1.0, potential=go.POT_HARMONIC, pot_scale=1.0,
+                      gamma=float(fx["gamma"]), p=int(fx["p"]), base_mode=-1,
+                      perturb_scale=float(fx["perturb_const"]) / float(fx["normal_const"]), bc_nn_scale=1.0,
+                      w_bc=10.0, w_norm=20.0, w_sym=0.0, dx=float(fx["dx"]))
+
+
 def bc_points(fx):
     return np.array([[float(fx["lb"])], [float(fx["ub"])]], dtype=np.float64)
 

@@ -46,6 +46,38 @@ def test_gpus_n_launches_n_ranks():
     assert out.returncode == 0 and len(recs) == 1 and recs[0]["rank"] == 1 and recs[0]["world"] == 2      # no second launch under torchrun
 
 
+def test_launcher_ends_the_job_when_a_rank_dies():
+    """One rank exits 3 while the others sit in what would be a collective: the launcher notices, terminates the siblings, names the
+    rank and exits non-zero within seconds -- it does not wait for the hung ranks; a job in which nobody finishes ends at the time limit."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["GPE_BENCH_LAUNCH_TEST"] = "fail:1"
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "2"], capture_output=True, text=True,
+                         timeout=120, cwd=ROOT, env=env)
+    assert out.returncode == 3, (out.returncode, out.stderr[-500:])
+    assert "rank 1 exited with code 3" in out.stderr and time.time() - t0 < 60
+    env["GPE_BENCH_LAUNCH_TEST"] = "hang"
+    env["GPE_BENCH_LAUNCH_TIMEOUT"] = "3"
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"], capture_output=True, text=True,
+                         timeout=120, cwd=ROOT, env=env)
+    assert out.returncode == 124 and "time limit" in out.stderr and time.time() - t0 < 60
+
+
+def test_scaling_default_is_strong_for_the_sharded_baseline_configs_at_8_gpus():
+    """--gpus 8 on cfg3 / cfg4 / cfg5 measures BASELINE's global sizes (strong scaling) unless --scaling says otherwise."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["GPE_BENCH_LAUNCH_TEST"] = "1"
+    for wl, gpus, extra, want in (("cfg3_2d_5x128", 8, [], "strong"), ("cfg3_2d_5x128", 2, [], "weak"), ("ns_2d_4x64", 8, [], "weak"),
+                                  ("cfg5_3d_6x256", 8, ["--scaling", "weak"], "weak")):
+        env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE=str(gpus))
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--workload", wl] + extra,
+                             capture_output=True, text=True, timeout=120, cwd=ROOT, env=env2)
+        rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        assert rec["scaling"] == want, (wl, gpus, rec)
+
+
 def test_strong_scaling_splits_the_baseline_global_grid():
     import bench
     for name in ("ns_2d_4x64", "cfg3_2d_5x128", "cfg5_3d_6x256"):
@@ -89,3 +121,9 @@ def test_bench_line_contract():
         assert k in r, k
     assert r["bound"] in ("hbm", "mfma") and 0.0 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert d["value"] > 1e7 and abs(d["value"] * d["ms_per_step"] * 1e-3 / d["config"]["points_per_gpu"] - 1.0) < 1e-6
+    # the timed block is repeated; the line reports the median block with min / max, and carries in-run correctness evidence
+    t = d["timing"]
+    assert t["blocks"] >= 5 and t["steps_per_block"] == 3 and t["ms_per_step_min"] <= d["ms_per_step"] <= t["ms_per_step_max"]
+    pc = d["parity_check"]
+    assert pc["ok"] is True and pc["grad_max_err_over_max_abs"] < 5e-5 and pc["mu_rel_err"] < 2e-5, pc
+    assert "mu_after_timed_steps" not in d and "trajectory" in d

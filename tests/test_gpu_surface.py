@@ -98,6 +98,41 @@ def test_class_surface_against_golden():
     model.close()
 
 
+@pytest.mark.parametrize("name", ["fx_vanilla_m0_g10_64x3.npz", "fx_vanilla_m0_gm4_32x3.npz"])
+def test_vanilla_pinn_branch_against_golden(name):
+    """use_perturbation=False (refine/harmonic_pinn_simulation.py:152-155, :205-208): the class methods on the engine against the
+    reference class's values (tests/golden/make_golden_refine_variants.py), and one engine step against the reference gradient."""
+    fx = H.load_fx(name)
+    layers = [int(v) for v in fx["layers"]]
+    model = refine.GrossPitaevskiiPINN(layers, mode=int(fx["mode"]), gamma=float(fx["gamma"]), use_perturbation=False)
+    sd = model.state_dict()
+    o = 0
+    for k, v in sd.items():
+        n = v.numel()
+        sd[k] = torch.from_numpy(fx["flat0"][o:o + n].reshape(v.shape).copy()); o += n
+    model.load_state_dict(sd)
+    X = torch.as_tensor(fx["x"], device="cuda")
+    nn_out = model.forward(X)
+    assert H.rel_err(nn_out.cpu().numpy(), fx["nn_out"]) < 1e-5
+    u_pred = float(fx["perturb_const"]) * nn_out / float(fx["normal_const"])
+    pde, lam = model.pde_loss(X, u_pred, float(fx["gamma"]), int(fx["p"]), "harmonic")
+    assert abs(float(lam) - float(fx["lam"])) < 2e-5 * abs(float(fx["lam"]))
+    assert abs(float(pde) - float(fx["pde_loss"])) < 2e-4 * float(fx["pde_loss"])
+    bl = model.boundary_loss(torch.tensor([[-10.0], [10.0]], device="cuda"), torch.zeros((2, 1), device="cuda"))
+    assert abs(float(bl) - float(fx["bc_loss"])) < 1e-5 * float(fx["bc_loss"]) + 1e-12
+    nl = model.normalization_loss(u_pred, float(fx["dx"]))
+    assert abs(float(nl) - float(fx["norm_loss"])) < 1e-3 * float(fx["norm_loss"])
+    model.close()
+    # the same problem as one engine step: loss and gradient of pde + 10 bc + 20 norm against the reference's autograd gradient
+    from tests.test_gpu_parity import make_engine
+    pb = H.problem_from_vanilla(fx)
+    eng = make_engine(pb, fx["flat0"], fx["x"], H.bc_points(fx))
+    sc = eng.step()
+    assert abs(sc["loss"] - float(fx["total"])) < 2e-4 * float(fx["total"]) and abs(sc["mu"] - float(fx["lam"])) < 2e-5 * abs(float(fx["lam"]))
+    assert H.rel_err(eng.get_grad(), fx["grad0"]) < 5e-4
+    eng.close()
+
+
 def test_end_to_end_mu_against_reference_notebook_output():
     """BASELINE metric "ground-state mu abs-error vs ref": the root notebook's own stdout (cell c22, Colab T4, unseeded) gives
     mu = 0.8948 for gamma = 1, mode 0, p = 3 at epoch 4500 of 5000 and 1.1125 for p = 2 (first-order
@@ -130,6 +165,23 @@ def test_gamma_continuation_against_independent_solver():
     for g in (0.0, 1.0, 2.0):
         assert abs(models[g].last_mu - exact[g]) < 2e-3, (g, models[g].last_mu, exact[g])
     assert abs(models[0.0].last_mu - 1.0) < 5e-5
+
+
+def test_attractive_interaction_driver_walks_gamma_downwards():
+    """refine/harmonic_pinn_simulation_negative_interaction_strength.py:271-299: gamma (there eta) < 0, continuation from 0 DOWNWARDS with
+    warm starts; lambda(gamma) against the fp64 Newton / finite-difference solver (oracle/gp_ground_state.py)."""
+    from oracle import gp_ground_state as gs
+    torch.manual_seed(0)
+    lb, ub, N = -10, 10, 4000
+    X = np.linspace(lb, ub, N).reshape(-1, 1)
+    gammas = [-2.0, -1.0, 0.0]                                        # handed over unsorted-ascending, trained 0, -1, -2
+    out = gpe_pinn.refine_negative.train_gpe_model(gammas, [0], 3, X, lb, ub, [1, 64, 64, 64, 1], 3001, 1e-7, 0.01, lr=1e-3, verbose=False)
+    models, hist = out[0][0], out[2][0]
+    assert list(models.keys()) == [0.0, -1.0, -2.0] and list(hist.keys()) == [0.0, -1.0, -2.0]
+    exact, _ = gs.ground_state_1d(gammas, c=1.0, vscale=1.0, n=2401)
+    for g in gammas:
+        assert abs(models[g].last_mu - exact[g]) < 2e-3, (g, models[g].last_mu, exact[g])
+    assert exact[-2.0] < exact[-1.0] < 1.0 and abs(models[0.0].last_mu - 1.0) < 5e-5
 
 
 def test_pretrain_on_analytical_solution():
@@ -222,7 +274,7 @@ def test_relobralo_balanced_steps_run_and_descend():
 
 
 # ---- second half of the BASELINE metric for the headline configurations: mu within 1e-3 of the independent fp64 ground truth ----
-@pytest.mark.parametrize("case,extra", [("ns_2d", []), ("cfg2_1d", [])])
+@pytest.mark.parametrize("case,extra", [("ns_2d", []), ("cfg2_1d", []), ("cfg3_2d", [])])
 def test_ground_state_mu_within_1e_3(case, extra, tmp_path):
     """tools/accuracy_nd.py: pre-training on the g = 0 Gaussian, gamma continuation to BASELINE's g with the variational energy
     term keeping the run on the ground state; mu (Rayleigh quotient of the engine) against oracle/gp_ground_truth.json
@@ -245,7 +297,8 @@ def test_refine_driver_against_reference_run(name):
     stage of clipped Adam are not bit-reproducible across implementations, so: lambda(gamma) to 2e-3 (the perturbation ansatz with
     q = 0.01 keeps it within 1e-3 of first-order perturbation theory in both runs), the history cadence exactly (one loss sample per
     10 epochs, one lambda / constraint sample per 100, up to the recorded stop epoch), normal_const to 5 %, the first recorded loss
-    of the first stage to 30 % (later stages: same order of magnitude), and the same early-stop DECISION per stage (stopped before the epoch budget or not)."""
+    of the first stage to 30 % (later stages: the warm-start contract, see below), and the same early-stop DECISION per stage (stopped
+    before the epoch budget or not)."""
     fx = H.load_fx(name)
     layers = [int(v) for v in fx["layers"]]
     N, epochs, tol = int(fx["N"]), int(fx["epochs"]), float(fx["tol"])
@@ -276,8 +329,21 @@ def test_refine_driver_against_reference_run(name):
             assert len(ref_loss) == ((int(e_ref) + 1 if int(e_ref) < epochs else epochs) + 9) // 10      # the reference keeps the same cadence
             if g == gammas[0]:        # fixed by the ansatz: 20 ((1 + q / max)^2 ... - 1)^2 right after the pre-training
                 assert abs(h["loss"][0] - ref_loss[0]) <= 0.3 * abs(ref_loss[0]) + 1e-6
-            else:                     # warm-started stages begin where the previous (chaotic) trajectory ended: same order of magnitude
-                assert 0.2 * ref_loss[0] <= h["loss"][0] <= 5.0 * ref_loss[0]
+            else:
+                # A warm-started stage begins where the previous one ended (:298-299), and where clipped Adam leaves the loss after a
+                # few hundred epochs is chaotic: it wanders over more than a decade in the reference's own runs, so the reference's
+                # number is not a yardstick (a band of 0.2x .. 5x around it passed or failed on rounding-level changes of the kernels).
+                # What IS fixed is the warm-start contract: the first loss of the stage is the loss of the PREVIOUS stage's returned
+                # model at the new gamma, evaluated through the class methods.
+                prev = models[mode][gammas[gammas.index(g) - 1]]
+                Xd = torch.as_tensor(X.astype(np.float32), device="cuda")
+                u_pred = prev.forward(Xd) * (0.01 / float(const[mode]))
+                pde, _ = prev.pde_loss(Xd, u_pred, g, 3, "harmonic")
+                bl = prev.boundary_loss(torch.tensor([[float(lb)], [float(ub)]], device="cuda"), torch.zeros((2, 1), device="cuda"))
+                nl = prev.normalization_loss(prev.get_complete_solution(Xd, u_pred), float(X[1, 0] - X[0, 0]))
+                warm = float(pde) + 10.0 * float(bl) + 20.0 * float(nl)
+                assert abs(h["loss"][0] - warm) <= 2e-3 * abs(warm) + 1e-7, (g, h["loss"][0], warm)
+                assert np.isfinite(ref_loss[0]) and ref_loss[0] > 0
             sd = models[mode][g].state_dict()
             assert [tuple(v.shape) for v in sd.values()] == [s for k in range(len(layers) - 1) for s in ((layers[k + 1], layers[k]), (layers[k + 1],))]
 

@@ -33,6 +33,28 @@ def test_refine_oplevel(name):
     assert H.rel_err(grad, fx["grad0"]) < 2e-4
 
 
+@pytest.mark.parametrize("name", ["fx_vanilla_m0_g10_64x3.npz", "fx_vanilla_m0_gm4_32x3.npz"])
+def test_vanilla_pinn_branch_oplevel(name):
+    """use_perturbation=False (refine/harmonic_pinn_simulation.py:152-155, :205-208; tests/golden/make_golden_refine_variants.py):
+    u = the scaled network output, no Hermite base; also with an attractive interaction (gamma < 0)."""
+    fx = H.load_fx(name)
+    pb = H.problem_from_vanilla(fx)
+    x = fx["x"].astype(np.float64)
+    flat = fx["flat0"].astype(np.float64)
+    out, _ = go.mlp_forward(go.unflatten(flat, pb.layers), x, pb.activation)
+    assert H.rel_err(out[0], fx["nn_out"]) < 1e-5
+    h = go.head_pde(pb, x, out)
+    assert H.rel_err(h["U"][0], fx["u"]) < 2e-6 and H.rel_err(h["U"][1], fx["u_x"]) < 5e-6 and H.rel_err(h["U"][2], fx["u_xx"]) < 2e-5
+    sc, grad, res = go.full_loss_and_grad(pb, flat, x, H.bc_points(fx))
+    assert abs(sc["mu"] - float(fx["lam"])) < 2e-5 * abs(float(fx["lam"]))
+    assert H.rel_err(res["residual"], fx["residual"]) < 1e-4
+    assert abs(sc["pde"] - float(fx["pde_loss"])) < 2e-4 * float(fx["pde_loss"])
+    assert abs(sc["bc"] - float(fx["bc_loss"])) < 1e-5 * float(fx["bc_loss"]) + 1e-12
+    assert abs(sc["norm"] - float(fx["norm_loss"])) < 1e-4 * float(fx["norm_loss"])
+    assert abs(sc["loss"] - float(fx["total"])) < 1e-4 * float(fx["total"])
+    assert H.rel_err(grad, fx["grad0"]) < 2e-4
+
+
 @pytest.mark.parametrize("name", H.nb_names())
 def test_notebook_oplevel(name):
     fx = H.load_fx(name)
@@ -242,6 +264,24 @@ def test_advanced_initialization_bit_exact():
         flavour = surface.refine if "refine" in name else surface.notebook
         flat = surface.seeded_reference_init(layers, mode, flavour.KIND)
         np.testing.assert_array_equal(flat, fx["flat0"], err_msg=name)
+
+
+def test_box_to_gaussian_seeded_construction_bit_exact():
+    """The residual-block flavour: torch.manual_seed(seed); GrossPitaevskiiPINN(layers, ...); model.apply(advanced_initialization)
+    gives the reference's weights bit for bit -- its constructor builds the network twice (refine/box_to_gaussian_pinn_simulation.py:90,
+    :98), i.e. two default-init draws precede the Xavier draw."""
+    import torch
+    import gpe_pinn
+    for name, seed in (("fx_box2gauss_m0_g0.npz", 0), ("fx_box2gauss_m1_g5_p4.npz", 3)):
+        fx = H.load_fx(name)
+        layers = [int(v) for v in fx["layers"]]
+        mode = int(fx["mode"])
+        torch.manual_seed(seed)
+        model = gpe_pinn.box_to_gaussian.GrossPitaevskiiPINN(layers, mode=mode, gamma=float(fx["gamma"]), L=float(fx["ub"]), use_residual=True)
+        model.apply(lambda m_: gpe_pinn.box_to_gaussian.advanced_initialization(m_, mode))
+        flat = np.concatenate([np.asarray(v, np.float32).ravel() for v in model.state_dict().values()])
+        np.testing.assert_array_equal(flat, fx["flat0"], err_msg=name)
+        assert list(model.state_dict().keys()) == [str(k) for k in fx["state_dict_keys"]]
 
 
 # ---- row f3: residual-block network of refine/box_to_gaussian_pinn_simulation.py (tests/golden/make_golden_box2gauss.py) ------------
