@@ -420,6 +420,7 @@ def main():
             for _ in range(k):
                 eng.step_distributed()
 
+    coll0 = eng.comm_info()["collectives"] if native else 0          # (the cross-check above issued some)
     run_steps(args.warmup)
     eng.synchronize()
     eng.profile_enable(True)           # HIP events around the two dominant kernels, on the engine's stream, over the timed region
@@ -507,7 +508,7 @@ def main():
                        "exchange": (("engine_rccl_stale1" if args.async_grad else "engine_rccl") if native else "torch_distributed") if use_dist else "none"},
             "per_gpu_points_per_s": value / world,
             "rccl_ranks": comm["world"] if native else (world if use_dist else 0),
-            "collectives_per_step": (comm["collectives"] / max(1, args.steps + args.warmup)) if native else (2 if use_dist else 0),
+            "collectives_per_step": ((comm["collectives"] - coll0) / max(1, steps_from_init)) if native else (2 if use_dist else 0),
             "exchange_crosscheck": xcheck,
             "trajectory": {"steps_from_seeded_init": steps_from_init, "loss": sc["loss"], "mu": sc["mu"],
                            "note": "state after the warm-up and timed steps from a random init -- NOT a converged eigenvalue; the "
