@@ -41,7 +41,7 @@ struct Phys {
 };
 
 // Indices into the double "sums" exchange buffer (all-reduced over ranks between phase 1 and 2).
-enum { S_NUM = 0, S_DEN = 1, S_SYM = 2, S_ORTH0 = 3, /* ..S_ORTH0+3 */ S_RZ_K = 7, S_RZ_P = 8, S_RZ_I = 9, S_COUNT = 12 };
+enum { S_NUM = 0, S_DEN = 1, S_SYM = 2, S_ORTH0 = 3, /* ..S_ORTH0+3 */ S_RZ_K = 7, S_RZ_P = 8, S_RZ_I = 9, S_RZ_L = 10 /* <L_z> of complex psi */, S_COUNT = 12 };
 // Local (replicated, never exchanged) double scalars.
 enum { LS_BC_SE2 = 0, LS_BC_CNT = 1, LS_COUNT = 4 };
 // Tail of the float gradient exchange buffer.

@@ -140,7 +140,8 @@ __global__ __launch_bounds__(1024) void k_update(int P, float* __restrict__ thet
         double riesz = 0.0;
         if (ph.w_riesz != 0.f) {
             const double fI = ph.riesz_kind == GPE_RIESZ_VARIATIONAL ? pow(I, -0.5 * (double)(ph.p - 1)) : 1.0;
-            riesz = (sums[S_RZ_K] + sums[S_RZ_P] + fI * sums[S_RZ_I]) / (ph.riesz_kind == GPE_RIESZ_SUM ? 1.0 : den);
+            const double Lrot = ph.complex_psi ? (double)ph.omega_rot * sums[S_RZ_L] : 0.0;      // rotating frame: - Omega <L_z>
+            riesz = (sums[S_RZ_K] + sums[S_RZ_P] + fI * sums[S_RZ_I] - Lrot) / (ph.riesz_kind == GPE_RIESZ_SUM ? 1.0 : den);
         }
         double loss = ph.w_pde * pde + ph.w_bc * bc + ph.w_norm * nrm + ph.w_sym * sym + ph.w_orth * orth + ph.w_riesz * riesz;
         if (mse_mode) {           // pre-training: loss = mean((NN - target)^2); plain Adam (no clip, no scheduler, no early stop)
@@ -389,7 +390,7 @@ static int setup_batch(gpe_engine* e, Batch& b, const float* x, int64_t n, int C
     if (with_head) {
         if ((rc = dev_alloc(e, &b, &b.u, (size_t)no * b.ld))) return rc;
         if ((rc = dev_alloc(e, &b, &b.Hu, (size_t)no * b.ld))) return rc;
-        if ((rc = dev_alloc(e, &b, &b.ux, (size_t)e->nd.dim * b.ld))) return rc;
+        if ((rc = dev_alloc(e, &b, &b.ux, (size_t)no * e->nd.dim * b.ld))) return rc;      // [n_out][dim][ld]
     }
     const int L = e->nd.n_lin - 1;
     if (e->path == GPE_PATH_FUSED) {
@@ -1057,7 +1058,8 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
     if (c.base_kind < 0 || c.base_kind > GPE_BASE_PRECOMPUTED) CFAIL("Unknown base kind: %d", c.base_kind);
     if (c.envelope < 0 || c.envelope > GPE_ENV_SIN) CFAIL("Unknown envelope: %d", c.envelope);
     if (c.envelope != GPE_ENV_NONE && (dim != 1 || no != 1)) CFAIL("the boundary factor needs dim=1, out=1");
-    if (c.w_riesz != 0.f && no != 1) CFAIL("the Riesz energy term needs real psi (out=1)");
+    if (c.w_riesz != 0.f && no != 1 && !(c.complex_psi && no == 2 && c.p == 3))
+        CFAIL("the Riesz energy term needs real psi (out=1) or complex psi (out=2) with p = 3");
     if (c.riesz_kind < 0 || c.riesz_kind > GPE_RIESZ_VARIATIONAL) CFAIL("Unknown Riesz kind: %d", c.riesz_kind);
     for (int i = 1; i < c.n_layers - 1; ++i)
         if (c.layers[i] < 1 || c.layers[i] > 1024) CFAIL("hidden width %d out of range", c.layers[i]);

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void k_head_pde(Phys ph, float base_norm, Pts 
     constexpr int D = C - 1 - E;
     __shared__ double red[4];
     double num = 0.0, den = 0.0, so[GPE_MAX_ORTH] = {0.0, 0.0, 0.0, 0.0};
-    double rzk = 0.0, rzp = 0.0, rzi = 0.0, bse = 0.0;
+    double rzk = 0.0, rzp = 0.0, rzi = 0.0, rzl = 0.0, bse = 0.0;
     // grid-stride: few workgroups, one double atomic each per sum (same-address atomics serialise at ~25 ns apiece)
     for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < N; m += (int64_t)gridDim.x * 256) {
         float xv[3] = {0.f, 0.f, 0.f};
@@ -109,13 +109,25 @@ __global__ __launch_bounds__(256) void k_head_pde(Phys ph, float base_norm, Pts 
             if (ph.w_riesz != 0.f) {            // Paper nb c6:L163-174 ; src/gross_pitaevskii_2D.py:112-151
                 float ak, ap, ai; bool nrm;
                 riesz_coefs(ph, ak, ap, ai, nrm);
-                const float u = U[0][0];
-                float g2 = 0.f;
+                float g2 = 0.f, rho = 0.f;
+                for (int o = 0; o < ph.n_out; ++o) {       // (complex psi: both components; first derivatives kept as [o][k])
+                    rho = fmaf(U[o][0], U[o][0], rho);
 #pragma unroll
-                for (int k = 0; k < D; ++k) { const float uk = U[0][1 + k]; ux_out[(int64_t)k * ld + m] = uk; g2 = fmaf(uk, uk, g2); }
+                    for (int k = 0; k < D; ++k) { const float uk = U[o][1 + k]; ux_out[(int64_t)(o * D + k) * ld + m] = uk; g2 = fmaf(uk, uk, g2); }
+                }
                 rzk += (double)(ak * g2);
-                rzp += (double)(ap * V * u * u);
-                rzi += (double)(ai * ipowf(fabsf(u), ph.p + 1));
+                rzp += (double)(ap * V * rho);
+                if (!ph.complex_psi) rzi += (double)(ai * ipowf(fabsf(U[0][0]), ph.p + 1));
+                else {                                     // |psi|^4 (p = 3) and the rotating-frame term: <L_z> = psi_r D psi_i - psi_i D psi_r, D = x d_y - y d_x
+                    rzi += (double)(ai * rho * rho);
+                    if constexpr (D >= 2) {
+                        if (ph.omega_rot != 0.f) {
+                            const float Dr = xv[0] * U[0][2] - xv[1] * U[0][1];
+                            const float Di = xv[0] * U[1][2] - xv[1] * U[1][1];
+                            rzl += (double)(U[0][0] * Di - U[1][0] * Dr);
+                        }
+                    }
+                }
             }
         }
     }
@@ -124,6 +136,7 @@ __global__ __launch_bounds__(256) void k_head_pde(Phys ph, float base_norm, Pts 
         t = block_sum_256(rzk, red); if (threadIdx.x == 0) atomicAdd(&sums[S_RZ_K], t);
         t = block_sum_256(rzp, red); if (threadIdx.x == 0) atomicAdd(&sums[S_RZ_P], t);
         t = block_sum_256(rzi, red); if (threadIdx.x == 0) atomicAdd(&sums[S_RZ_I], t);
+        if (ph.complex_psi && ph.omega_rot != 0.f) { t = block_sum_256(rzl, red); if (threadIdx.x == 0) atomicAdd(&sums[S_RZ_L], t); }
     }
     if (n_pde < N) {
         double t = block_sum_256(bse, red);
@@ -200,12 +213,28 @@ __global__ __launch_bounds__(256) void k_seed_pde(Phys ph, Pts x, const float* _
                         // VARIATIONAL: the interaction sum carries fI = I^(-(p-1)/2), I = dx sum u^2 (energy of the normalised state)
                         const float fI = ph.riesz_kind == GPE_RIESZ_VARIATIONAL ? powf((float)sums[S_DEN] * ph.dx, -0.5f * (float)(ph.p - 1)) : 1.0f;
                         const float cI = ph.riesz_kind == GPE_RIESZ_VARIATIONAL ? 0.5f * (float)(ph.p + 1) : 1.0f;
-                        const float Erz = nrm ? (float)((sums[S_RZ_K] + sums[S_RZ_P] + (double)(cI * fI) * sums[S_RZ_I]) / sums[S_DEN]) : 0.0f;
-                        const float uu = u[0];
-                        const float sg = uu < 0.f ? -1.f : 1.f;
-                        Ub[0] += ph.w_riesz * ((2.f * ap * V * uu + ai * fI * (float)(ph.p + 1) * sg * ipowf(fabsf(uu), ph.p)) - 2.f * Erz * uu) / dnm;
+                        const double Lrot = ph.complex_psi ? (double)ph.omega_rot * sums[S_RZ_L] : 0.0;
+                        const float Erz = nrm ? (float)((sums[S_RZ_K] + sums[S_RZ_P] + (double)(cI * fI) * sums[S_RZ_I] - Lrot) / sums[S_DEN]) : 0.0f;
+                        const float uu = u[o];
+                        float dint;
+                        if (!ph.complex_psi) {
+                            const float sg = uu < 0.f ? -1.f : 1.f;
+                            dint = ai * fI * (float)(ph.p + 1) * sg * ipowf(fabsf(uu), ph.p);
+                        } else dint = ai * fI * (float)(ph.p + 1) * (u[0] * u[0] + u[1] * u[1]) * uu;       // d rho^2 / d psi_o = 4 rho psi_o
+                        Ub[0] += ph.w_riesz * ((2.f * ap * V * uu + dint) - 2.f * Erz * uu) / dnm;
 #pragma unroll
-                        for (int k = 0; k < D; ++k) Ub[1 + k] += ph.w_riesz * 2.f * ak * ux_in[(int64_t)k * ld + m] / dnm;
+                        for (int k = 0; k < D; ++k) Ub[1 + k] += ph.w_riesz * 2.f * ak * ux_in[(int64_t)(o * D + k) * ld + m] / dnm;
+                        if constexpr (D >= 2) {
+                            if (ph.complex_psi && ph.omega_rot != 0.f) {        // - Omega <L_z> / den
+                                const float Om = ph.omega_rot, wq = ph.w_riesz / dnm;
+                                const int q = 1 - o;                            // the other component
+                                const float Dq = xv[0] * ux_in[(int64_t)(q * D + 1) * ld + m] - xv[1] * ux_in[(int64_t)(q * D + 0) * ld + m];
+                                const float sgn = o == 0 ? 1.f : -1.f;          // d<L_z>/d psi_r = D psi_i ; d<L_z>/d psi_i = -D psi_r
+                                Ub[0] += wq * (-Om) * sgn * Dq;
+                                Ub[1] += wq * (-Om) * sgn * (xv[1] * u[q]);     // d<L_z>/d(d_x psi_r) = y psi_i ; /d(d_x psi_i) = -y psi_r
+                                Ub[2] += wq * (-Om) * sgn * (-xv[0] * u[q]);    // d<L_z>/d(d_y psi_r) = -x psi_i ; /d(d_y psi_i) = x psi_r
+                            }
+                        }
                     }
                 }
                 if (ph.complex_psi && ph.omega_rot != 0.f && D >= 2) {

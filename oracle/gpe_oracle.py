@@ -367,11 +367,24 @@ def loss_and_grad(pb: Problem, flat: np.ndarray, x: np.ndarray, x_bc: Optional[n
     for j in range(n_orth):
         sums[f'orth{j}'] = float((orth[j].astype(dt)[:, None] * u).sum(dtype=acc))
     if pb.w_riesz != 0.0:                                        # Paper nb c6:L163-174 (dx cancels in the quotient) ; 2D: src/...2D.py:112-151
-        assert pb.n_out == 1
         ak, ap, ai, _ = riesz_coefs(pb)
         sums['rz_k'] = float((dt.type(ak) * (U[1:1 + d] ** 2).sum(axis=0)).sum(dtype=acc))
         sums['rz_p'] = float((dt.type(ap) * V[:, None] * u * u).sum(dtype=acc))
-        sums['rz_i'] = float((dt.type(ai) * _ipow(np.abs(u), pb.p + 1)).sum(dtype=acc))
+        if not pb.complex_psi:
+            sums['rz_i'] = float((dt.type(ai) * _ipow(np.abs(u), pb.p + 1)).sum(dtype=acc))
+            sums['rz_l'] = 0.0
+        else:
+            # complex psi (north star; no reference code): |psi|^(p+1) = rho^((p+1)/2), and the rotating-frame term -Omega <L_z>,
+            # <L_z> = sum psi_r (x d_y - y d_x) psi_i - psi_i (x d_y - y d_x) psi_r   (quadratic in psi like the kinetic and potential sums)
+            assert pb.n_out == 2 and pb.p == 3
+            rho = (u * u).sum(axis=1)
+            sums['rz_i'] = float((dt.type(ai) * rho * rho).sum(dtype=acc))
+            sums['rz_l'] = 0.0
+            if pb.omega_rot != 0.0:
+                xx, yy = x[:, 0].astype(dt), x[:, 1].astype(dt)
+                Dr = xx * U[2, :, 0] - yy * U[1, :, 0]
+                Di = xx * U[2, :, 1] - yy * U[1, :, 1]
+                sums['rz_l'] = float((u[:, 0] * Di - u[:, 1] * Dr).sum(dtype=acc))
     # symmetry term: two value-only passes (notebook c6:L143-147)
     sym = None
     if pb.w_sym != 0.0:
@@ -412,7 +425,7 @@ def loss_and_grad(pb: Problem, flat: np.ndarray, x: np.ndarray, x_bc: Optional[n
         rz_norm = riesz_coefs(pb)[3]
         if pb.riesz_kind == RIESZ_VARIATIONAL:
             fI = (tot['den'] * pb.dx) ** (-0.5 * (pb.p - 1))
-        E_rz = (tot['rz_k'] + tot['rz_p'] + fI * tot['rz_i']) / (tot['den'] if rz_norm else 1.0)
+        E_rz = (tot['rz_k'] + tot['rz_p'] + fI * tot['rz_i'] - pb.omega_rot * tot.get('rz_l', 0.0)) / (tot['den'] if rz_norm else 1.0)
     else:
         E_rz = 0.0
     res.update(L_norm=L_norm, L_bc=L_bc, L_orth=L_orth, L_sym=L_sym, L_riesz=E_rz)
@@ -450,12 +463,26 @@ def loss_and_grad(pb: Problem, flat: np.ndarray, x: np.ndarray, x_bc: Optional[n
         ak, ap, ai, rz_norm = riesz_coefs(pb)
         dnm = dt.type(tot['den']) if rz_norm else dt.type(1.0)
         cI = 0.5 * (pb.p + 1) if pb.riesz_kind == RIESZ_VARIATIONAL else 1.0
-        Eq = dt.type((tot['rz_k'] + tot['rz_p'] + cI * fI * tot['rz_i']) / tot['den']) if rz_norm else dt.type(0.0)
+        Eq = dt.type((tot['rz_k'] + tot['rz_p'] + cI * fI * tot['rz_i'] - pb.omega_rot * tot.get('rz_l', 0.0)) / tot['den']) if rz_norm else dt.type(0.0)
         wz = dt.type(pb.w_riesz)
-        Ub[0] = Ub[0] + wz * ((2 * dt.type(ap) * V[:, None] * u
-                               + dt.type(ai * fI * (pb.p + 1)) * np.sign(u + (u == 0)) * _ipow(np.abs(u), pb.p)) - 2 * Eq * u) / dnm
+        if not pb.complex_psi:
+            dint = dt.type(ai * fI * (pb.p + 1)) * np.sign(u + (u == 0)) * _ipow(np.abs(u), pb.p)
+        else:
+            dint = dt.type(ai * fI * (pb.p + 1)) * (u * u).sum(axis=1, keepdims=True) * u          # d rho^2 / d psi_o = 4 rho psi_o (p = 3)
+        Ub[0] = Ub[0] + wz * ((2 * dt.type(ap) * V[:, None] * u + dint) - 2 * Eq * u) / dnm
         for k in range(d):
             Ub[1 + k] = Ub[1 + k] + wz * dt.type(2 * ak) * U[1 + k] / dnm
+        if pb.complex_psi and pb.omega_rot != 0.0:               # -Omega <L_z> / den: seeds on psi and on its first derivatives
+            Om = dt.type(pb.omega_rot)
+            xx, yy = x[:, 0].astype(dt), x[:, 1].astype(dt)
+            Dr = xx * U[2, :, 0] - yy * U[1, :, 0]
+            Di = xx * U[2, :, 1] - yy * U[1, :, 1]
+            Ub[0, :, 0] += wz * (-Om * Di) / dnm
+            Ub[0, :, 1] += wz * (Om * Dr) / dnm
+            Ub[1, :, 0] += wz * (-Om * yy * u[:, 1]) / dnm       # d<L_z>/d(d_x psi_r) = y psi_i
+            Ub[2, :, 0] += wz * (Om * xx * u[:, 1]) / dnm        # d<L_z>/d(d_y psi_r) = -x psi_i
+            Ub[1, :, 1] += wz * (Om * yy * u[:, 0]) / dnm        # d<L_z>/d(d_x psi_i) = -y psi_r
+            Ub[2, :, 1] += wz * (-Om * xx * u[:, 0]) / dnm       # d<L_z>/d(d_y psi_i) = x psi_r
     if pb.complex_psi and pb.omega_rot != 0.0:
         Om = dt.type(pb.omega_rot)
         xx, yy = x[:, 0], x[:, 1]

@@ -178,10 +178,18 @@ def epoch_losses(pb: go.Problem, net: nn.Sequential, X: torch.Tensor, x_bc=None,
         else:
             ak, ap, ai, nrm = go.riesz_coefs(pb)
             S = torch.sum(u ** 2)
-            inter = ai * torch.sum(torch.abs(u) ** (pb.p + 1))
+            if pb.complex_psi:                               # |psi|^(p+1) = rho^((p+1)/2)
+                inter = ai * torch.sum((u * u).sum(dim=1) ** (0.5 * (pb.p + 1)))
+            else:
+                inter = ai * torch.sum(torch.abs(u) ** (pb.p + 1))
             if kind == go.RIESZ_VARIATIONAL:                 # energy of the normalised state u / sqrt(dx sum u^2)
                 inter = inter * (pb.dx * S) ** (-0.5 * (pb.p - 1))
-            riesz = ak * torch.sum(grads1[0] ** 2) + ap * torch.sum(V * u ** 2) + inter
+            riesz = ak * sum(torch.sum(g1 ** 2) for g1 in grads1) + ap * torch.sum(V * u ** 2) + inter
+            if pb.complex_psi and pb.omega_rot != 0.0:       # rotating frame: - Omega <L_z>, L_z = -i (x d_y - y d_x)
+                xx, yy = X[:, 0:1], X[:, 1:2]
+                Dr = xx * grads1[0][:, 1:2] - yy * grads1[0][:, 0:1]
+                Di = xx * grads1[1][:, 1:2] - yy * grads1[1][:, 0:1]
+                riesz = riesz - pb.omega_rot * torch.sum(u[:, 0:1] * Di - u[:, 1:2] * Dr)
             if nrm:
                 riesz = riesz / S
         total = total + pb.w_riesz * riesz

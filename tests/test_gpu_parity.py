@@ -87,6 +87,12 @@ CASES = {
                           dx=36 / 400), 400, True),
     "2d_riesz_variational": (dict(layers=[2, 64, 64, 64, 64, 1], gamma=500.0, w_riesz=2.0, riesz_kind=go.RIESZ_VARIATIONAL, dx=36 / 900),
                              900, True),
+    # complex psi in the rotating frame with the variational energy E[psi / |psi|] - Omega <L_z> (what keeps cfg4 on the vortex-lattice
+    # state; no reference code: oracle = definition, cross-checked against fp64 autograd in tests/test_oracle_autograd.py)
+    "2d_complex_rot_variational": (dict(layers=[2, 64, 64, 64, 2], complex_psi=True, gamma=30.0, omega_rot=0.8, w_riesz=1.5,
+                                        riesz_kind=go.RIESZ_VARIATIONAL, dx=36 / 600), 600, True),
+    "2d_128x6_complex_rot_variational_cfg4": (dict(layers=[2, 128, 128, 128, 128, 128, 128, 2], complex_psi=True, gamma=500.0, omega_rot=0.8,
+                                                   w_riesz=1.0, riesz_kind=go.RIESZ_VARIATIONAL, dx=36 / 400), 400, True),
     "3d_riesz_variational": (dict(layers=[3, 128, 128, 128, 1], gamma=100.0, omega=(1.0, 1.4, 2.0), w_riesz=1.0,
                                   riesz_kind=go.RIESZ_VARIATIONAL, dx=0.01), 500, True),
     # residual-block networks (refine/box_to_gaussian_pinn_simulation.py:52-63,100-130): generic set

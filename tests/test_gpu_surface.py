@@ -290,6 +290,24 @@ def test_ground_state_mu_within_1e_3(case, extra, tmp_path):
     assert d["density_rel_l2"] <= 5e-3 and abs(d["energy"] - d["energy_ref"]) <= 1e-3
 
 
+def test_rotating_trap_vortex_lattice_against_the_grid_solver(tmp_path):
+    """BASELINE configs[3] (2D rotating trap, Omega = 0.8, g = 500, complex psi, [2,128x6,2]): tools/accuracy_cfg4.py trains the engine
+    from the vortex-seeded state to a vortex lattice; oracle/gp_rotating_2d.py (fp64 spectral, preconditioned CG on the sphere) runs
+    from the SAME seed.  Stated tolerances: |mu - mu_ref| <= 2e-3 and |E - E_ref| <= 1e-3 (measured 3e-4 / 2e-5), the
+    same number of vortices, <L_z> to 1e-2, |psi|^2 to 10 % in relative L2 after the best rigid rotation (the lattice as a whole may
+    turn: isotropic trap)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "acc4.json")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "accuracy_cfg4.py"), "--no-basin", "--out", out],
+                       capture_output=True, text=True, timeout=1200, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    d = json.load(open(out))
+    assert d["vortices"] == d["vortices_ref"] >= 15 and d["antivortices"] == 0, (d["vortices"], d["vortices_ref"])
+    assert d["mu_abs_err"] <= 2e-3 and d["E_abs_err"] <= 1e-3, (d["mu"], d["mu_ref"], d["E"], d["E_ref"])
+    assert abs(d["lz"] - d["lz_ref"]) <= 1e-2 and d["density_rel_l2_best_rotation"] <= 0.1
+
+
 # ---- the continuation driver against a seeded run of the REFERENCE's own train_gpe_model (tests/golden/make_golden_refine_driver.py) --
 @pytest.mark.parametrize("name", ["fx_refdriver_m0_3stages.npz", "fx_refdriver_m1_2stages.npz", "fx_refdriver_m0_earlystop.npz"])
 def test_refine_driver_against_reference_run(name):

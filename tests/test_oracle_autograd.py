@@ -29,6 +29,10 @@ CASES = {
     "2d_riesz_variational": (dict(layers=[2, 16, 16, 16, 1], gamma=500.0, w_riesz=2.0, riesz_kind=go.RIESZ_VARIATIONAL, dx=0.02), 45),
     "3d_riesz_variational_p2": (dict(layers=[3, 12, 12, 1], gamma=30.0, p=2, abs_power=True, omega=(1.0, 1.4, 2.0), w_riesz=1.5,
                                      riesz_kind=go.RIESZ_VARIATIONAL, dx=0.02), 30),
+    "2d_complex_rot_variational": (dict(layers=[2, 16, 16, 16, 2], complex_psi=True, gamma=50.0, omega_rot=0.8, w_riesz=1.5,
+                                        riesz_kind=go.RIESZ_VARIATIONAL, dx=0.02), 40),
+    "2d_complex_variational_norot": (dict(layers=[2, 12, 12, 2], complex_psi=True, gamma=20.0, w_riesz=1.0, riesz_kind=go.RIESZ_VARIATIONAL,
+                                          dx=0.02), 30),
     "2d_riesz_paper": (dict(layers=[2, 12, 12, 1], gamma=10.0, w_riesz=1.0, riesz_kind=go.RIESZ_PAPER, dx=0.02), 30),
     "1d_shifted_beta_trap": (dict(layers=[1, 16, 16, 1], activation=1, kinetic_coeff=1.0, pot_scale=0.35, omega=(3.0, 1.0, 1.0), pot_a=0.7,
                                   gamma=4.0, dx=0.1), 40),
