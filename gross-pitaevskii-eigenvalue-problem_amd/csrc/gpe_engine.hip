@@ -1981,7 +1981,8 @@ int gpe_set_power(gpe_engine* e, int p) {
 int gpe_set_perturb_scale(gpe_engine* e, float s) { if (!e) return GPE_ERR_INVALID; e->cfg.perturb_scale = s; fill_phys(e); return GPE_OK; }
 int gpe_set_loss_weights(gpe_engine* e, const float w[6]) {
     if (!e || !w) return GPE_ERR_INVALID;
-    if (w[5] != 0.f && e->nd.n_out != 1) FAIL(e, GPE_ERR_INVALID, "the Riesz energy term needs real psi (out=1)");
+    if (w[5] != 0.f && e->nd.n_out != 1 && !(e->cfg.complex_psi && e->nd.n_out == 2 && e->cfg.p == 3))
+        FAIL(e, GPE_ERR_INVALID, "the Riesz energy term needs real psi (out=1) or complex psi (out=2) with p = 3");
     if ((w[3] != 0.f) != (e->cfg.w_sym != 0.f)) FAIL(e, GPE_ERR_INVALID, "the symmetry term cannot be switched on/off after bind_points");
     e->cfg.w_pde = w[0]; e->cfg.w_bc = w[1]; e->cfg.w_norm = w[2]; e->cfg.w_sym = w[3]; e->cfg.w_orth = w[4]; e->cfg.w_riesz = w[5];
     fill_phys(e);

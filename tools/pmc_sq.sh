@@ -10,7 +10,7 @@ R=$PWD
 mkdir -p $out
 export TMPDIR=/tmp
 cd /tmp
-CMD="python3 $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-alt-mode"
+CMD="python3 $R/bench.py --workload $wl --steps 3 --warmup 1 --blocks 1 --no-parity-check --no-cpu-baseline --no-alt-mode"
 pass() {   # name, counters...
     name=$1; shift
     rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out/pmc_$name -- $CMD > /dev/null 2> $out/pmc_$name.err || { echo "pass $name failed"; tail -5 $out/pmc_$name.err; return 1; }
