@@ -239,6 +239,49 @@ GPE_DEV float potential_at(const Phys& ph, const float* xv, const float* Vpre, i
     }
 }
 
+// Seeds dLoss/d(output jets) of ONE collocation point for real psi without orthogonality / Riesz terms -- what k_seed_pde
+// (gpe_head.h) writes to Ob for such a point, as a function: the reverse kernel of small batches forms them itself (SeedArgs, below)
+// instead of reading them back, one launch fewer per step.  Returns r^2 of the point.  Same operations in the same order as the kernel.
+template <int C, int E>
+GPE_DEV float seed_point(const Phys& ph, const float* xv, float V, float u, float Hu, float lam, float I, float (&ob)[C]) {
+    constexpr int D = C - 1 - E;
+    const float r = Hu - lam * u;
+    const float cr = (float)(2.0 * (double)ph.w_pde / ph.n_global);
+    const float rb = cr * r;
+    const float dint = ph.abs_power ? ph.gamma * (float)ph.p * ipowf(fabsf(u), ph.p - 1) : ph.gamma * (float)ph.p * ipowf(u, ph.p - 1);
+    float ub = rb * (V + dint - lam);
+    const float cn = ph.w_norm * 4.0f * (I - 1.0f) * ph.dx;
+    ub += cn * u;
+    float Ub[C];
+    Ub[0] = ub;
+#pragma unroll
+    for (int j = 0; j < D; ++j) Ub[1 + j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < E; ++j) Ub[1 + D + j] = -ph.kin * rb;
+    if constexpr (D == 1) {
+        if (ph.envelope == GPE_ENV_SIN) {      // adjoint of psi = o f
+            float f, f1, f2;
+            envelope_at(ph, xv[0], f, f1, f2);
+            const float u0 = Ub[0], u1 = Ub[1], u2 = Ub[2];
+            Ub[0] = fmaf(f, u0, fmaf(f1, u1, f2 * u2));
+            Ub[1] = fmaf(f, u1, 2.0f * f1 * u2);
+            Ub[2] = f * u2;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) ob[c] = ph.perturb_scale * Ub[c];
+    return r * r;
+}
+// what a reverse kernel needs to form the seeds of the collocation rows itself (boundary rows riding in the batch keep the seeds
+// the head kernel wrote to Ob)
+struct SeedArgs {
+    Phys ph;
+    const float* Vpre; const float* u; const float* Hu;     // [ld] each (n_out = 1)
+    const double* sums;                                      // S_NUM, S_DEN of this step (complete: the head kernel has finished)
+    double* sum_r2;                                          // += sum of r^2 over the collocation rows
+    int64_t n_pde;                                           // rows [0, n_pde) are collocation points
+};
+
 // block-wide sum of a double over 256 threads -> valid in thread 0
 GPE_DEV double block_sum_256(double v, double* red /* >= 4 doubles of LDS */) {
 #pragma unroll

@@ -95,15 +95,15 @@ __global__ __launch_bounds__(1024) void k_update_part(int P, const float* __rest
 }
 
 template <bool MULTI>
-__global__ __launch_bounds__(1024) void k_update(int P, float* __restrict__ theta, float* __restrict__ am,
-                                                  float* __restrict__ av, const float* __restrict__ grad,
-                                                  const double* __restrict__ sums_in, const double* __restrict__ lsums_in,
-                                                  Phys ph, OptCfg oc, OptDev* __restrict__ od,
-                                                  gpe_scalars* __restrict__ hist, int cap, gpe_scalars* __restrict__ last,
-                                                  double bc_cnt, int do_update, int mse_mode, NetDesc nd, int H,
-                                                  float* __restrict__ Wpk, float* __restrict__ WpkT, int n_pack,
-                                                  double* __restrict__ dbl, int n_dbl, double* __restrict__ dbl_keep,
-                                                  const UpdSnap* __restrict__ snap) {
+GPE_DEV void update_core(int P, float* __restrict__ theta, float* __restrict__ am,
+                         float* __restrict__ av, const float* __restrict__ grad,
+                         const double* __restrict__ sums_in, const double* __restrict__ lsums_in,
+                         const Phys& ph, const OptCfg& oc, OptDev* __restrict__ od,
+                         gpe_scalars* __restrict__ hist, int cap, gpe_scalars* __restrict__ last,
+                         double bc_cnt, int do_update, int mse_mode, const NetDesc& nd, int H,
+                         float* __restrict__ Wpk, float* __restrict__ WpkT, int n_pack,
+                         double* __restrict__ dbl, int n_dbl, double* __restrict__ dbl_keep,
+                         const UpdSnap* __restrict__ snap) {
     __shared__ double red[16];
     __shared__ float s_coef, s_ss, s_b2s;
     __shared__ int s_skip, s_book, s_frozen;
@@ -236,6 +236,20 @@ __global__ __launch_bounds__(1024) void k_update(int P, float* __restrict__ thet
     if constexpr (!MULTI) for (int i = threadIdx.x; i < n_pack; i += 1024) pack_weight_element(nd, H, theta, Wpk, WpkT, i);
 }
 
+template <bool MULTI>
+__global__ __launch_bounds__(1024) void k_update(int P, float* __restrict__ theta, float* __restrict__ am,
+                                                  float* __restrict__ av, const float* __restrict__ grad,
+                                                  const double* __restrict__ sums_in, const double* __restrict__ lsums_in,
+                                                  Phys ph, OptCfg oc, OptDev* __restrict__ od,
+                                                  gpe_scalars* __restrict__ hist, int cap, gpe_scalars* __restrict__ last,
+                                                  double bc_cnt, int do_update, int mse_mode, NetDesc nd, int H,
+                                                  float* __restrict__ Wpk, float* __restrict__ WpkT, int n_pack,
+                                                  double* __restrict__ dbl, int n_dbl, double* __restrict__ dbl_keep,
+                                                  const UpdSnap* __restrict__ snap) {
+    update_core<MULTI>(P, theta, am, av, grad, sums_in, lsums_in, ph, oc, od, hist, cap, last, bc_cnt, do_update, mse_mode, nd, H,
+                       Wpk, WpkT, n_pack, dbl, n_dbl, dbl_keep, snap);
+}
+
 // closes the reverse phase: adds the boundary-batch gradient (computed on the side stream) and fills the exchange tail
 __global__ void k_tail(float* __restrict__ grad, const float* __restrict__ add, int P, const double* dsc) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -281,6 +295,9 @@ struct gpe_engine {
     float *theta = nullptr, *am = nullptr, *av = nullptr, *grad = nullptr;   // grad: P + GT_COUNT
     double* dbl = nullptr;         // [S_COUNT sums | LS_COUNT local | 4 misc]
     OptDev* od = nullptr;
+    bool fuse_seed = true;         // small batches: the pipelined reverse kernel forms the seeds itself (GPE_FUSE_SEED=0: k_seed_pde)
+    bool seedf_now = false;        // ... for the reverse pass being enqueued
+    int64_t fuse_seed_max = 65536; // ... up to this many points (beyond, the redundant seed arithmetic of the four waves costs more than the launch)
     UpdSnap* upd_snap = nullptr;   // multi-workgroup update (P >= UPD_MULTI_MIN): partial norms + snapshot of sums / optimiser state
     gpe_scalars *hist = nullptr, *last = nullptr;
     int cap = 65536;
@@ -550,6 +567,15 @@ static bool coop_shape(gpe_engine* e) {
     if (e->H <= 64) return maps >= 1 && maps <= 3;
     return e->H == 128 && maps >= 1 && maps <= 5 && e->nd.dim <= 2 && e->coop128;    // 8 waves per workgroup, weights streamed from L2
 }
+static int bwd_kind(gpe_engine* e, const Batch& b);
+static bool use_pipe(gpe_engine* e, int C);
+// small batches of the common problem class (real psi, no orthogonality / Riesz / symmetry terms) on the pipelined reverse kernel:
+// the kernel forms the seeds itself and k_seed_pde is not launched
+static bool seed_in_reverse(gpe_engine* e) {
+    return e->fuse_seed && e->path == GPE_PATH_FUSED && !e->wide && e->nd.n_out == 1 && !e->cfg.complex_psi && e->ph.n_orth == 0 &&
+           e->cfg.w_riesz == 0.f && e->cfg.w_sym == 0.f && e->main.C >= 3 && e->main.n > 0 && e->main.n <= e->fuse_seed_max &&
+           use_pipe(e, e->main.C) && bwd_kind(e, e->main) == 3;
+}
 static int bwd_kind(gpe_engine* e, const Batch& b) {
     if (coop_shape(e) && e->coop != 0 && (e->coop == 1 || (b.n + 15) / 16 <= e->coop_max_tiles)) return 3;
     if (e->H > 64 || !staged_batch(e, b)) return 0;
@@ -577,6 +603,11 @@ static void set_pipe_lds(int bytes) {
         (void)hipFuncSetAttribute((const void*)f_backward_pipe<HH, CC, EE, NO, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         (void)hipFuncSetAttribute((const void*)f_backward_pipe<HH, CC, EE, NO, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         (void)hipFuncSetAttribute((const void*)f_backward_pipe<HH, CC, EE, NO, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if constexpr (NO == 1 && CC >= 3) {
+            (void)hipFuncSetAttribute((const void*)f_backward_pipe<HH, CC, EE, 1, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute((const void*)f_backward_pipe<HH, CC, EE, 1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute((const void*)f_backward_pipe<HH, CC, EE, 1, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        }
     }
 }
 template <int HH, int CC, int EE, int NO>
@@ -592,10 +623,22 @@ static void launch_coop_no(gpe_engine* e, Batch& b, unsigned grid, size_t lds) {
             return;
         }
         if constexpr (!(HH == 64 && CC == 5)) if (use_pipe(e, CC)) {       // (H = 64 in 3D: two workgroups' exchange buffers exceed the LDS)
+            if constexpr (NO == 1 && CC >= 3) {
+                if (e->seedf_now && &b == &e->main) {       // small batch: the kernel forms the seeds itself (k_seed_pde was not launched)
+                    const SeedArgs sa{e->ph, b.V, b.u, b.Hu, (const double*)e->sums(), e->dsc(), e->n_pde};
+                    switch (e->nd.n_lin - 2) {
+                        case 1: hipLaunchKernelGGL((f_backward_pipe<HH, CC, EE, 1, 1, true>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS, sa); break;
+                        case 2: hipLaunchKernelGGL((f_backward_pipe<HH, CC, EE, 1, 2, true>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS, sa); break;
+                        default: hipLaunchKernelGGL((f_backward_pipe<HH, CC, EE, 1, 3, true>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS, sa); break;
+                    }
+                    return;
+                }
+            }
+            const SeedArgs none{};
             switch (e->nd.n_lin - 2) {
-                case 1: hipLaunchKernelGGL((f_backward_pipe<HH, CC, EE, NO, 1>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
-                case 2: hipLaunchKernelGGL((f_backward_pipe<HH, CC, EE, NO, 2>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
-                default: hipLaunchKernelGGL((f_backward_pipe<HH, CC, EE, NO, 3>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
+                case 1: hipLaunchKernelGGL((f_backward_pipe<HH, CC, EE, NO, 1>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS, none); break;
+                case 2: hipLaunchKernelGGL((f_backward_pipe<HH, CC, EE, NO, 2>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS, none); break;
+                default: hipLaunchKernelGGL((f_backward_pipe<HH, CC, EE, NO, 3>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS, none); break;
             }
             return;
         }
@@ -779,6 +822,7 @@ static int mlp_forward(gpe_engine* e, Batch& b, bool store) {
 }
 
 static int bc_join(gpe_engine* e);
+static double bc_count(gpe_engine* e);
 static int launch_tail(gpe_engine* e, bool add_bc);
 static int dp_allreduce_after(gpe_engine* e, void* buf, size_t count, ncclDataType_t dt, hipEvent_t ev);
 // Gradient of one batch into e->grad: assigned (first reverse pass of the step) or accumulated.  close: this is the last reverse pass of the step -- join the boundary batch's side stream, add its
@@ -1018,7 +1062,8 @@ int gpe_active_kernels(gpe_engine* e, char* buf, size_t n) {
         else snprintf(f, sizeof f, "f_forward<%d,%d,%d,%d,%s>", e->H, b.C, b.E, e->nd.n_out,
                       (e->H <= 64 && e->fwd_wlds && staged_batch(e, b)) ? "wlds" : "l2");
         const int kind = bwd_kind(e, b);
-        if (kind == 3 && use_pipe(e, b.C)) snprintf(r, sizeof r, "f_backward_pipe<%d,%d,%d,%d,%d>", e->H, b.C, b.E, e->nd.n_out, maps);
+        if (kind == 3 && use_pipe(e, b.C)) snprintf(r, sizeof r, "f_backward_pipe<%d,%d,%d,%d,%d%s>", e->H, b.C, b.E, e->nd.n_out, maps,
+                                                    seed_in_reverse(e) ? ",seeds" : "");
         else if (kind == 3) snprintf(r, sizeof r, "f_backward_coop<%d,%d,%d,%d,%d%s>", e->H, b.C, b.E, e->nd.n_out, maps > 5 ? 5 : maps,
                                 (e->bwd_b6 && e->H <= 64) ? ",b6" : "");
         else if (kind == 2) snprintf(r, sizeof r, "f_backward<%d,%d,%d,%d,wlds,racc%d>", e->H, b.C, b.E, e->nd.n_out, maps > 3 ? 3 : maps);
@@ -1132,6 +1177,11 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
     {
         const char* envu = getenv("GPE_UPDATE_MULTI");               // 0: the single-workgroup update at every size
         if (ok && e->P >= UPD_MULTI_MIN && !(envu && atoi(envu) == 0)) ok = alloc((void**)&e->upd_snap, sizeof(UpdSnap));
+        const char* envf3 = getenv("GPE_FUSE_SEED");
+        e->fuse_seed = !(envf3 && atoi(envf3) == 0);
+        const char* envf4 = getenv("GPE_FUSE_SEED_MAX");
+        if (envf4) e->fuse_seed_max = atoll(envf4);
+
     }
     if (ok && e->path == GPE_PATH_FUSED) {
         e->nslab = (H >= 128) ? std::max(e->nslab_g, e->num_cu) : e->num_cu * 2;     // H = 128: 16 atomic slabs, or one per workgroup (cooperative)
@@ -1546,9 +1596,14 @@ int gpe_step_backward(gpe_engine* e) {
     if (!e) return GPE_ERR_INVALID;
     if (e->phase != 1) FAIL(e, GPE_ERR_STATE, "step_backward without step_begin");
     int rc;
-    if ((rc = launch_seed_pde(e, nullptr, 1))) return rc;
     const bool with_sym = e->cfg.w_sym != 0.f;
-    if ((rc = mlp_backward(e, e->main, /*close=*/!with_sym))) return rc;
+    // small batches of the common problem class (real psi, no orthogonality / Riesz / symmetry terms) on the pipelined reverse
+    // kernel: the seeds are formed inside it
+    e->seedf_now = seed_in_reverse(e);
+    if (!e->seedf_now && (rc = launch_seed_pde(e, nullptr, 1))) return rc;
+    rc = mlp_backward(e, e->main, /*close=*/!with_sym);
+    e->seedf_now = false;
+    if (rc) return rc;
     if (with_sym) {
         hipLaunchKernelGGL(k_seed_sym, dim3(cdiv(e->n_pde, 256)), dim3(256), 0, e->stream, e->ph, e->sym.O, e->sym.Ob,
                            e->n_pde, e->sym.ld);

@@ -1192,11 +1192,14 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_coop(NetDesc nd, const fl
 // conflict-free because the 16-byte fragment slots of that buffer are XOR-swizzled (slot of lane (m, q) = (m ^ q) + 16 q: the
 // ds_read_b128 lane groups still cover each bank row once, and the 32 lanes of a b32 read group land on 32 distinct banks).
 // LDS: 2 x (C NT 256) x 2 x 4 B = 64 KB for NS, two workgroups per CU.
-template <int H, int C, int E, int NOUT, int NHH>
+// SEEDF (small batches, real psi without orthogonality / Riesz terms): the seeds dLoss/d(output jets) of the collocation rows are formed
+// here from u, H u and the step's global sums (seed_point, gpe_common.h) instead of being read from Ob -- k_seed_pde is not launched.
+template <int H, int C, int E, int NOUT, int NHH, bool SEEDF = false>
 __global__ __launch_bounds__(H * 4, 2) void f_backward_pipe(NetDesc nd, const float* __restrict__ theta,
                                                             const float* __restrict__ WpkT, Pts x,
                                                             const float* __restrict__ stored, const float* __restrict__ Ob,
-                                                            float* __restrict__ gslab, int64_t N, int64_t ld, int Ppad) {
+                                                            float* __restrict__ gslab, int64_t N, int64_t ld, int Ppad, SeedArgs sa) {
+    static_assert(!SEEDF || NOUT == 1, "seeds in the reverse kernel: real psi");
     constexpr int D = C - 1 - E, NT = H / 16, NTHR = 64 * NT;
     constexpr int L = NHH + 1;                       // index of the output map; hidden layers 0..L-1
     constexpr int ZSZ = C * NT * 256;                // floats per exchange buffer (z fragments and X^T tiles alike: F_TILE = 256)
@@ -1258,16 +1261,30 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_pipe(NetDesc nd, const fl
     // ---- pieces of a tile's work ---------------------------------------------------------------------------------------------
     float xv[3] = {0.f, 0.f, 0.f};
     float ob[NOUT][C];
+    double r2acc = 0.0;                                // SEEDF: sum of r^2 over this workgroup's collocation rows (wave 0, q = 0 lanes)
+    float s_lam = 0.f, s_I = 0.f;
+    if constexpr (SEEDF) { s_lam = (float)(sa.sums[S_NUM] / sa.sums[S_DEN]); s_I = (float)sa.sums[S_DEN] * sa.ph.dx; }
     auto load_point = [&](int64_t tile) {              // coordinates and output-jet adjoints of the lane's point
         const int64_t pm = tile * 16 + m;
         const bool valid = pm < N;
         const int64_t pl = valid ? pm : N - 1;
 #pragma unroll
         for (int k = 0; k < 3; ++k) if (k < dim) xv[k] = pts_at(x, pl, dim, k);
+        if constexpr (SEEDF) {
+            if (valid && pm < sa.n_pde) {                  // collocation row: seeds from u, H u, lambda, the norm integral
+                const float V = potential_at(sa.ph, xv, sa.Vpre, pm);
+                const float r2 = seed_point<C, E>(sa.ph, xv, V, sa.u[pm], sa.Hu[pm], s_lam, s_I, ob[0]);
+                if (w == 0 && q == 0) r2acc += (double)r2;
+            } else {                                       // boundary row riding in the batch (seeded by the head kernel) / padding
+#pragma unroll
+                for (int c = 0; c < C; ++c) ob[0][c] = valid ? Ob[(int64_t)c * ld + pm] : 0.f;
+            }
+        } else {
 #pragma unroll
         for (int o = 0; o < NOUT; ++o)
 #pragma unroll
             for (int c = 0; c < C; ++c) ob[o][c] = valid ? Ob[((int64_t)c * NOUT + o) * ld + pm] : 0.f;
+        }
     };
     // stored (t, z_k, z_L) of hidden layer h >= 1 of a tile, this wave's slice: the tile's block [L-1][C][NT][256] behind one descriptor
     auto load_st = [&](int64_t tile, int h, f32x4 (&st)[C]) {
@@ -1490,6 +1507,14 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_pipe(NetDesc nd, const fl
 #pragma unroll
                 for (int kt = 0; kt < NT; ++kt)
                     dwacc[0][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(zt[s2], xf[kt][s2], dwacc[0][kt], 0, 0, 0);
+        }
+    }
+    if constexpr (SEEDF) {                              // sum of r^2: lanes 0..15 of wave 0 hold the workgroup's partial sums
+        if (w == 0) {
+            double t = r2acc;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
+            if (le == 0 && t != 0.0) atomicAdd(sa.sum_r2, t);
         }
     }
     // ---- the per-lane sums: across the 16 point lanes, into the workgroup's LDS block (zeroed above; every wave owns its rows) --------
