@@ -94,6 +94,16 @@ __global__ __launch_bounds__(1024) void k_update_part(int P, const float* __rest
     }
 }
 
+// one Adam element, torch's op order (refine/...:359-361): shared by every update loop so that they agree bit for bit
+GPE_DEV void adam_element(float graw, float& m, float& v, float& th, float coef, float ss, float b2s, float b1, float b2, float eps) {
+#pragma clang fp contract(off)      // torch's kernels round every product before the add; and every call site must round alike
+    const float g = graw * coef;
+    m = m + (g - m) * (1.0f - b1);                 // exp_avg.lerp_(grad, 1-beta1)
+    v = v * b2 + (1.0f - b2) * g * g;              // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1-beta2)
+    const float denom = sqrtf(v) / b2s + eps;
+    th = th - ss * (m / denom);                    // param.addcdiv_(exp_avg, denom, value=-step_size)
+}
+
 template <bool MULTI>
 GPE_DEV void update_core(int P, float* __restrict__ theta, float* __restrict__ am,
                          float* __restrict__ av, const float* __restrict__ grad,
@@ -103,7 +113,17 @@ GPE_DEV void update_core(int P, float* __restrict__ theta, float* __restrict__ a
                          double bc_cnt, int do_update, int mse_mode, const NetDesc& nd, int H,
                          float* __restrict__ Wpk, float* __restrict__ WpkT, int n_pack,
                          double* __restrict__ dbl, int n_dbl, double* __restrict__ dbl_keep,
-                         const UpdSnap* __restrict__ snap) {
+                         const UpdSnap* __restrict__ snap, int pack_mode) {
+    // pack_mode (one workgroup): 1 = repack the hidden-hidden weights by a gather pass over the updated parameters (also writes the
+    // bf16 pieces the opt-in split-bf16 kernels read); 2 = every thread SCATTERS its updated weights into the two packed copies inside
+    // the Adam loop (no second pass, no barrier, no bf16 pieces).  REG_E: up to this many elements per thread are loaded ONCE, at the
+    // top, into registers (gradient for the norm, Adam moments and parameters behind it): at the reference's batch sizes this kernel
+    // is a chain of dependent round trips to L2 -- it took 16.6 us of a 52 us step at 4 000 points -- and every load issued early is
+    // one round trip less.
+    constexpr int REG_E = 13;                                 // (13 312 parameters: the 4 x 64 networks of BASELINE; 16 would spill at 128 registers)
+    const bool cached = !MULTI && P <= REG_E * 1024 && !(pack_mode & 4);      // (bit 2 of pack_mode: tuning switch GPE_UPDATE_CACHE=0)
+    pack_mode &= 3;
+    float cg[REG_E], cm[REG_E], cv[REG_E], ct[REG_E];
     __shared__ double red[16];
     __shared__ float s_coef, s_ss, s_b2s;
     __shared__ int s_skip, s_book, s_frozen;
@@ -116,6 +136,17 @@ GPE_DEV void update_core(int P, float* __restrict__ theta, float* __restrict__ a
     const int lo = MULTI ? blockIdx.x * upd_chunk(P) : 0, hi = MULTI ? min(P, lo + upd_chunk(P)) : P;
     if constexpr (!MULTI) {
         double acc = 0.0;
+        if (cached) {
+#pragma unroll
+            for (int k = 0; k < REG_E; ++k) { const int i = threadIdx.x + k * 1024; cg[k] = i < P ? grad[i] : 0.f; }
+#pragma unroll
+            for (int k = 0; k < REG_E; ++k) {
+                const int i = threadIdx.x + k * 1024;
+                if (i < P) { cm[k] = am[i]; cv[k] = av[i]; ct[k] = theta[i]; }
+            }
+#pragma unroll
+            for (int k = 0; k < REG_E; ++k) { const double g = cg[k]; acc += g * g; }          // (same order as the loop below)
+        } else
         for (int i = threadIdx.x; i < P; i += 1024) { double g = grad[i]; acc += g * g; }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
@@ -215,16 +246,38 @@ GPE_DEV void update_core(int P, float* __restrict__ theta, float* __restrict__ a
             }
         }
     }
-    if (!s_skip) {
+    if (!s_skip && cached) {
+        const float coef = s_coef, ss = s_ss, b2s = s_b2s;
+        const float b1 = oc.beta1, b2 = oc.beta2, eps = oc.eps;
+        const int lg = H == 64 ? 6 : (H == 32 ? 5 : (H == 128 ? 7 : 8)), NT = H >> 4, maps = nd.n_lin - 2;
+#pragma unroll
+        for (int k = 0; k < REG_E; ++k) {
+            const int i = threadIdx.x + k * 1024;
+            if (i < P) {
+                float m = cm[k], v = cv[k], th = ct[k];
+                adam_element(cg[k], m, v, th, coef, ss, b2s, b1, b2, eps);
+                theta[i] = th;
+                am[i] = m; av[i] = v;
+                if (pack_mode == 2 && n_pack > 0) {             // W_j[n][kk] of a hidden-hidden map -> its slots in Wpk / WpkT (pack_weight_element inverted)
+                    for (int j = 1; j <= maps; ++j) {
+                        const int e = i - nd.offW[j];
+                        if (e >= 0 && e < H * H) {
+                            const int n = e >> lg, kk = e & (H - 1);
+                            const int nt = n >> 4, kt = kk >> 4;
+                            Wpk[(((j - 1) * NT + nt) * NT + kt) * 256 + ((n & 15) + 16 * ((kk & 15) >> 2)) * 4 + (kk & 3)] = th;
+                            WpkT[(((j - 1) * NT + kt) * NT + nt) * 256 + ((kk & 15) + 16 * ((n & 15) >> 2)) * 4 + (n & 3)] = th;
+                        }
+                    }
+                }
+            }
+        }
+    } else if (!s_skip) {
         const float coef = s_coef, ss = s_ss, b2s = s_b2s;
         const float b1 = oc.beta1, b2 = oc.beta2, eps = oc.eps;
         for (int i = lo + threadIdx.x; i < hi; i += 1024) {
-            float g = grad[i] * coef;
-            float m = am[i], v = av[i];
-            m = m + (g - m) * (1.0f - b1);                 // exp_avg.lerp_(grad, 1-beta1)
-            v = v * b2 + (1.0f - b2) * g * g;              // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1-beta2)
-            float denom = sqrtf(v) / b2s + eps;
-            theta[i] = theta[i] - ss * (m / denom);        // param.addcdiv_(exp_avg, denom, value=-step_size)
+            float m = am[i], v = av[i], th = theta[i];
+            adam_element(grad[i], m, v, th, coef, ss, b2s, b1, b2, eps);
+            theta[i] = th;
             am[i] = m; av[i] = v;
         }
     }
@@ -233,7 +286,10 @@ GPE_DEV void update_core(int P, float* __restrict__ theta, float* __restrict__ a
     __syncthreads();
     // (stale-gradient mode: this step's sums are kept for the NEXT update, which applies this step's gradient)
     if (lead) for (int i = threadIdx.x; i < n_dbl; i += 1024) { if (dbl_keep) dbl_keep[i] = dbl[i]; dbl[i] = 0.0; }
-    if constexpr (!MULTI) for (int i = threadIdx.x; i < n_pack; i += 1024) pack_weight_element(nd, H, theta, Wpk, WpkT, i);
+    if constexpr (!MULTI) {
+        if (pack_mode != 2 || !cached || s_skip)                  // (a skipped update leaves the parameters, and with them the packed copies, as they were -- but a repack is harmless)
+            for (int i = threadIdx.x; i < n_pack; i += 1024) pack_weight_element(nd, H, theta, Wpk, WpkT, i);
+    }
 }
 
 template <bool MULTI>
@@ -245,9 +301,9 @@ __global__ __launch_bounds__(1024) void k_update(int P, float* __restrict__ thet
                                                   double bc_cnt, int do_update, int mse_mode, NetDesc nd, int H,
                                                   float* __restrict__ Wpk, float* __restrict__ WpkT, int n_pack,
                                                   double* __restrict__ dbl, int n_dbl, double* __restrict__ dbl_keep,
-                                                  const UpdSnap* __restrict__ snap) {
+                                                  const UpdSnap* __restrict__ snap, int pack_mode) {
     update_core<MULTI>(P, theta, am, av, grad, sums_in, lsums_in, ph, oc, od, hist, cap, last, bc_cnt, do_update, mse_mode, nd, H,
-                       Wpk, WpkT, n_pack, dbl, n_dbl, dbl_keep, snap);
+                       Wpk, WpkT, n_pack, dbl, n_dbl, dbl_keep, snap, pack_mode);
 }
 
 // closes the reverse phase: adds the boundary-batch gradient (computed on the side stream) and fills the exchange tail
@@ -295,6 +351,7 @@ struct gpe_engine {
     float *theta = nullptr, *am = nullptr, *av = nullptr, *grad = nullptr;   // grad: P + GT_COUNT
     double* dbl = nullptr;         // [S_COUNT sums | LS_COUNT local | 4 misc]
     OptDev* od = nullptr;
+    bool update_cache = true;      // single-workgroup update: register-cached elements + scatter packing (GPE_UPDATE_CACHE=0: the two-pass form)
     bool fuse_seed = true;         // small batches: the pipelined reverse kernel forms the seeds itself (GPE_FUSE_SEED=0: k_seed_pde)
     bool seedf_now = false;        // ... for the reverse pass being enqueued
     int64_t fuse_seed_max = 65536; // ... up to this many points (beyond, the redundant seed arithmetic of the four waves costs more than the launch)
@@ -1176,7 +1233,11 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
               alloc((void**)&e->orth_dev, 8 * sizeof(float*));
     {
         const char* envu = getenv("GPE_UPDATE_MULTI");               // 0: the single-workgroup update at every size
-        if (ok && e->P >= UPD_MULTI_MIN && !(envu && atoi(envu) == 0)) ok = alloc((void**)&e->upd_snap, sizeof(UpdSnap));
+        const char* envum = getenv("GPE_UPDATE_MULTI_MIN");          // tests: the multi-workgroup form from this many parameters on
+        const int multi_min = envum ? atoi(envum) : UPD_MULTI_MIN;
+        if (ok && e->P >= multi_min && !(envu && atoi(envu) == 0)) ok = alloc((void**)&e->upd_snap, sizeof(UpdSnap));
+        const char* envuc = getenv("GPE_UPDATE_CACHE");
+        e->update_cache = !(envuc && atoi(envuc) == 0);
         const char* envf3 = getenv("GPE_FUSE_SEED");
         e->fuse_seed = !(envf3 && atoi(envf3) == 0);
         const char* envf4 = getenv("GPE_FUSE_SEED_MAX");
@@ -1625,11 +1686,11 @@ static void launch_update(gpe_engine* e, const float* grad, const double* sums, 
         hipLaunchKernelGGL(k_update_part, dim3(UPD_G), dim3(1024), 0, e->stream, e->P, grad, sums, lsums, e->od, e->upd_snap);
         hipLaunchKernelGGL(k_update<true>, dim3(UPD_G), dim3(1024), 0, e->stream, e->P, e->theta, e->am, e->av, grad, sums, lsums, e->ph,
                            e->oc, e->od, e->hist, e->cap, e->last, bc_cnt, do_update, mse_mode, e->nd, e->H, e->Wpk, e->WpkT, n_pack, e->dbl,
-                           (int)(S_COUNT + LS_COUNT + 4), dbl_keep, (const UpdSnap*)e->upd_snap);
+                           (int)(S_COUNT + LS_COUNT + 4), dbl_keep, (const UpdSnap*)e->upd_snap, 1);
     } else {
         hipLaunchKernelGGL(k_update<false>, dim3(1), dim3(1024), 0, e->stream, e->P, e->theta, e->am, e->av, grad, sums, lsums, e->ph,
                            e->oc, e->od, e->hist, e->cap, e->last, bc_cnt, do_update, mse_mode, e->nd, e->H, e->Wpk, e->WpkT, n_pack, e->dbl,
-                           (int)(S_COUNT + LS_COUNT + 4), dbl_keep, (const UpdSnap*)nullptr);
+                           (int)(S_COUNT + LS_COUNT + 4), dbl_keep, (const UpdSnap*)nullptr, ((e->fwd_b6 || e->bwd_b6 || e->H > 64) ? 1 : 2) | (e->update_cache ? 0 : 5));
     }
 }
 static double bc_count(gpe_engine* e) {

@@ -1229,36 +1229,6 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_pipe(NetDesc nd, const fl
     // exchange buffers start as zeros: the first interval's deferred product (no tile before it) then adds nothing -- no special case
     for (int i = tix; i < 4 * ZSZ / 4; i += NTHR) reinterpret_cast<f32x4*>(ZB)[i] = (f32x4)(0.f);
     stage_layer0<H>(w0s, theta, nd, NTHR, tix);
-    f32x4 wreg[NHH][NT];                               // K-slices of W_j^T: A operands of abar[16w..] = sum_nt W_j^T[16w.., 16nt..] z[16nt..]
-#pragma unroll
-    for (int a = 0; a < NHH; ++a)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-            wreg[a][nt] = *reinterpret_cast<const f32x4*>(&WpkT[(size_t)a * H * H + ((w * NT + nt) * 64 + lane) * 4]);
-    f32x4 dwacc[NHH][NT];                              // rows 16w..16w+15 of dW_j, column tile kt
-#pragma unroll
-    for (int a = 0; a < NHH; ++a)
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt) dwacc[a][kt] = (f32x4)(0.f);
-    // small-parameter gradients of this wave's slice: per-lane sums over all tiles (see f_backward_coop), or per-tile reductions
-    constexpr bool SREG = (C * NHH <= 12);
-    constexpr bool PREF = GPE_PIPE_PREFETCH && NOUT == 1;   // (complex psi: twice the output-jet adjoints in flight would spill)
-    constexpr bool G0REG = SREG && GPE_PIPE_G0REG;       // layer-0 sums per lane too (12 more registers in 2D)
-    f32x4 dbacc[NHH], g0acc[4], gwoacc[NOUT];
-    float gboacc[NOUT];
-#pragma unroll
-    for (int a = 0; a < NHH; ++a) dbacc[a] = (f32x4)(0.f);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) g0acc[k] = (f32x4)(0.f);
-#pragma unroll
-    for (int o = 0; o < NOUT; ++o) { gwoacc[o] = (f32x4)(0.f); gboacc[o] = 0.f; }
-    // the weight fragments have landed before the tile loop is entered, and the compiler knows it: else its wait-count bookkeeping
-    // (loop-entry state merged with the back edge) puts vmcnt waits in front of the first product phase of every tile, where
-    // they stall the matrix instructions on the stored-activation loads that were only just requested
-    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
-    __syncthreads();
-
-    // ---- pieces of a tile's work ---------------------------------------------------------------------------------------------
     float xv[3] = {0.f, 0.f, 0.f};
     float ob[NOUT][C];
     double r2acc = 0.0;                                // SEEDF: sum of r^2 over this workgroup's collocation rows (wave 0, q = 0 lanes)
@@ -1292,6 +1262,45 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_pipe(NetDesc nd, const fl
 #pragma unroll
         for (int c = 0; c < C; ++c) st[c] = buf_load4(rS, (unsigned)lane * 16u, (unsigned)((((h - 1) * C + c) * NT + w) * 1024));
     };
+    f32x4 wreg[NHH][NT];                               // K-slices of W_j^T: A operands of abar[16w..] = sum_nt W_j^T[16w.., 16nt..] z[16nt..]
+#pragma unroll
+    for (int a = 0; a < NHH; ++a)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            wreg[a][nt] = *reinterpret_cast<const f32x4*>(&WpkT[(size_t)a * H * H + ((w * NT + nt) * 64 + lane) * 4]);
+    f32x4 dwacc[NHH][NT];                              // rows 16w..16w+15 of dW_j, column tile kt
+#pragma unroll
+    for (int a = 0; a < NHH; ++a)
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) dwacc[a][kt] = (f32x4)(0.f);
+    // small-parameter gradients of this wave's slice: per-lane sums over all tiles (see f_backward_coop), or per-tile reductions
+    constexpr bool SREG = (C * NHH <= 12);
+    constexpr bool PREF = GPE_PIPE_PREFETCH && NOUT == 1;   // (complex psi: twice the output-jet adjoints in flight would spill)
+    constexpr bool G0REG = SREG && GPE_PIPE_G0REG;       // layer-0 sums per lane too (12 more registers in 2D)
+    f32x4 dbacc[NHH], g0acc[4], gwoacc[NOUT];
+    float gboacc[NOUT];
+#pragma unroll
+    for (int a = 0; a < NHH; ++a) dbacc[a] = (f32x4)(0.f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g0acc[k] = (f32x4)(0.f);
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) { gwoacc[o] = (f32x4)(0.f); gboacc[o] = 0.f; }
+    // the first tile's point data and top-layer stored jets are requested here, beside the weight fragments (one L2 / HBM round trip
+    // instead of two before the first product -- a workgroup of a 4 000-point batch has ONE tile)
+    int64_t tile = vb;
+    const int64_t tend = ntiles;
+    f32x4 stl0[C];
+    if (tile < tend) {
+        load_point(tile);
+        if constexpr (L - 1 >= 1) load_st(tile, L - 1, stl0);
+    }
+    // the weight fragments have landed before the tile loop is entered, and the compiler knows it: else its wait-count bookkeeping
+    // (loop-entry state merged with the back edge) puts vmcnt waits in front of the first product phase of every tile, where
+    // they stall the matrix instructions on the stored-activation loads that were only just requested
+    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
+    __syncthreads();
+
+    // ---- pieces of a tile's work ---------------------------------------------------------------------------------------------
     // z of a map's output, own slice, into the write-side buffer: B operand of everybody's adjoint product after the next barrier
     auto publish_z = [&](const f32x4 (&zb)[C], float* zw) {
 #pragma unroll
@@ -1344,15 +1353,12 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_pipe(NetDesc nd, const fl
         }
     };
     // ---- first tile: output map, z of the top hidden layer into buffer 0 ------------------------------------------------------------
-    int64_t tile = vb;
-    const int64_t tend = ntiles;
     int par = 0;                                       // exchange buffers the next product phase READS
     f32x4 st[C];                                       // stored jets in flight for the next activation adjoint
     if (tile < tend) {
-        load_point(tile);
-        f32x4 stl[C], zb[C];
-        if constexpr (L - 1 >= 1) load_st(tile, L - 1, stl); else layer0_st<H, C, E>(w0s, xv, w, q, stl);
-        output_stage(stl, zb);
+        f32x4 zb[C];
+        if constexpr (L - 1 < 1) layer0_st<H, C, E>(w0s, xv, w, q, stl0);
+        output_stage(stl0, zb);
         bias_sum(zb[0], NHH - 1);
         publish_z(zb, ZB);
         if constexpr (NHH - 1 >= 1) load_st(tile, NHH - 1, st);

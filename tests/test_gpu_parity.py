@@ -614,6 +614,47 @@ def test_kernel_variants_agree(kw, N, envs):
         assert len(seen) == len(envs), f"switches selected only {sorted(seen)}"
 
 
+@pytest.mark.parametrize("layers,sym,sched", [([1, 32, 32, 32, 32, 1], 5.0, go.SCHED_PLATEAU), ([1, 64, 64, 64, 1], 0.0, go.SCHED_COSINE_LOSS),
+                                              ([2, 64, 64, 64, 64, 1], 0.0, go.SCHED_CONST)])
+def test_update_kernel_forms_are_bit_identical(layers, sym, sched):
+    """The single-workgroup update has two forms: elements cached in registers from the top of the kernel with the repacked weights
+    SCATTERED from the Adam loop (default up to 13 312 parameters), and the two-pass form (GPE_UPDATE_CACHE=0: reload, then a gather
+    pass that repacks).  Same arithmetic, same summation order: 30 steps must agree bit for bit -- which also proves the scatter
+    addressing, since from the second step on every forward / reverse pass reads the scattered copies.  The multi-workgroup form
+    (large P; forced here with GPE_UPDATE_MULTI_MIN=1) sums |g|^2 in another order: equal to rounding."""
+    import os
+    d = layers[0]
+    N = 700
+    rng = np.random.default_rng(3)
+    x = (np.linspace(-8, 8, N).reshape(-1, 1) if d == 1 else rng.uniform(-4, 4, (N, d))).astype(np.float32)
+    flat = (rng.normal(0, 0.3, go.param_count(layers))).astype(np.float32)
+    kw = dict(layers=layers, gamma=1.0, p=3, base_mode=0 if d == 1 else -1, base_deriv=1, w_sym=sym, dx=16.0 / N, lr=1e-3, sched=sched)
+
+    def run(env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            eng = Engine(GPEConfig(**kw))
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        eng.set_params(flat)
+        eng.bind_points(torch.as_tensor(x, device="cuda"))
+        if d == 1:
+            eng.bind_boundary(torch.tensor([[-8.0], [8.0]], device="cuda"))
+        tr = [eng.step()["loss"] for _ in range(30)]
+        th = eng.get_params()
+        eng.close()
+        return np.array(tr), th
+
+    la, ta = run({})
+    lb, tb = run({"GPE_UPDATE_CACHE": "0"})
+    np.testing.assert_array_equal(la, lb)
+    np.testing.assert_array_equal(ta, tb)
+    lc, tc = run({"GPE_UPDATE_MULTI_MIN": "1"})
+    assert np.abs(lc - la).max() <= 1e-5 * np.abs(la).max() and np.abs(tc - ta).max() < 1e-5
+
+
 # ---- orthogonality penalty (north star; no reference code: the oracle is the definition, tests/test_oracle_autograd.py) --------
 ORTH_CASES = {
     "1d_two_modes": (dict(layers=[1, 64, 64, 64, 1], gamma=3.0, base_mode=2, w_orth=7.0, dx=12 / 799), 800, 2),

@@ -4,7 +4,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
-upd = [i for i, n in enumerate(names) if n.startswith("k_update")]
+upd = [i for i, n in enumerate(names) if "k_update" in n and "part" not in n]
 a, b = upd[len(upd) // 2], upd[len(upd) // 2 + 1]
 t0 = int(rows[a]["End_Timestamp"])
 prev_end = t0
