@@ -396,7 +396,7 @@ def main():
     xcheck = None
     if native:
         eng.comm_init(rank, world)
-        if world > 1:
+        if world > 1 or os.environ.get("GPE_BENCH_FORCE_XCHECK"):     # (the variable: run the check at world 1 too -- tests)
             # the engine-native exchange against the torch.distributed protocol, from the same state, before anything is timed: a
             # mismatch on any rank sends the whole job to the torch protocol (labelled in the line) instead of timing a wrong path
             ok, detail = dp_crosscheck(eng, flat)

@@ -95,13 +95,16 @@ def test_strong_scaling_splits_the_baseline_global_grid():
 @pytest.mark.gpu
 def test_bench_native_exchange_path_world_1():
     """RANK set (as under torchrun): torch.distributed(nccl) for the rendezvous + the engine's own RCCL communicator for the data path."""
-    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577",
+               GPE_BENCH_FORCE_XCHECK="1")           # also run the N > 1 cross-check of the two exchange paths (here at world 1)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cfg2_1d_4x64", "--steps", "3", "--warmup", "1",
                           "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["config"]["exchange"] == "engine_rccl" and d["rccl_ranks"] == 1 and d["n_gpus"] == 1
     assert abs(d["collectives_per_step"] - 2.0) < 1e-9
+    x = d["exchange_crosscheck"]
+    assert x["ok"] is True and x["grad_rel"] < 1e-5 and x["loss_rel"] < 1e-5, x
 
 
 @pytest.mark.gpu
