@@ -186,23 +186,26 @@ class Engine:
     _comm_seq = 0          # communicators created by this process: every rank creates them in the same order
 
     def comm_init(self, rank: int, world: int, store=None, key: str = "gpe_comm_id"):
-        """Create the engine's own RCCL communicator.  The 128-byte ncclUniqueId travels through `store` (anything with
-        set/get, e.g. the TCPStore of an initialised torch.distributed group, the default when none is given) under a key that
-        is unique per communicator (`key`/<sequence number>): a second engine, or a communicator re-created after comm_destroy,
-        never reads the id of an earlier one."""
+        """Create the engine's own RCCL communicator.  The 128-byte ncclUniqueId of rank 0 reaches the other ranks through
+        `store` (anything with set / get; the key is unique per communicator -- `key`/<sequence number> -- so a second engine, or a
+        communicator re-created after comm_destroy, never reads the id of an earlier one) or, when none is given, by
+        torch.distributed.broadcast_object_list over the initialised default group."""
         key = f"{key}/{Engine._comm_seq}"
         Engine._comm_seq += 1
-        if store is None and world > 1:
-            import torch.distributed as dist
-            store = dist.distributed_c10d._get_default_store()
         ident = (C.c_ubyte * capi.GPE_COMM_ID_BYTES)()
         if rank == 0:
             self._chk(self.lib.gpe_comm_unique_id(self._h, ident))
-            if store is not None:
+        if store is not None:                              # caller's key-value store (set / get)
+            if rank == 0:
                 store.set(key, bytes(ident))
-        else:
-            raw = store.get(key)
-            C.memmove(ident, bytes(raw), capi.GPE_COMM_ID_BYTES)
+            else:
+                C.memmove(ident, bytes(store.get(key)), capi.GPE_COMM_ID_BYTES)
+        elif world > 1:                                    # default: the initialised torch.distributed group, public API only
+            import torch.distributed as dist
+            box = [bytes(ident) if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            if rank != 0:
+                C.memmove(ident, box[0], capi.GPE_COMM_ID_BYTES)
         self._chk(self.lib.gpe_comm_init(self._h, ident, int(rank), int(world)))
 
     def comm_info(self) -> dict:

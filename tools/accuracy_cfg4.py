@@ -197,7 +197,7 @@ rel_l2 = float(np.sqrt(((dens - dref) ** 2).sum() / (dref ** 2).sum()))
 # the trap is isotropic: the lattice as a whole may turn (a zero mode of the energy) -- density error also after the best rigid rotation
 best = (rel_l2, 0.0)
 Xd64 = X.astype(np.float64)
-for th in np.linspace(-0.25, 0.25, 101):
+for th in np.linspace(-0.55, 0.55, 221):          # (a triangular lattice repeats every pi/3)
     c_, s_ = math.cos(th), math.sin(th)
     Xr = np.stack([c_ * Xd64[:, 0] - s_ * Xd64[:, 1], s_ * Xd64[:, 0] + c_ * Xd64[:, 1]], axis=1)
     dr = R.interp_density(bx, ref["psi"], np.clip(Xr, -11.9, 11.9))
