@@ -280,6 +280,10 @@ struct SeedArgs {
     const double* sums;                                      // S_NUM, S_DEN of this step (complete: the head kernel has finished)
     double* sum_r2;                                          // += sum of r^2 over the collocation rows
     int64_t n_pde;                                           // rows [0, n_pde) are collocation points
+    // the forward kernel ran the head itself (HeadArgs, gpe_head.h) and left one (num, den, bse) triple per workgroup: every workgroup
+    // of the reverse kernel adds the triples in index order (deterministic), workgroup 0 also files the totals for the update kernel
+    const double* slots; int nslots;
+    double* sums_out; double* lsums_out;
 };
 
 // block-wide sum of a double over 256 threads -> valid in thread 0

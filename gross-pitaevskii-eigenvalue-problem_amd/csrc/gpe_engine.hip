@@ -355,6 +355,11 @@ struct gpe_engine {
     bool fuse_seed = true;         // small batches: the pipelined reverse kernel forms the seeds itself (GPE_FUSE_SEED=0: k_seed_pde)
     bool seedf_now = false;        // ... for the reverse pass being enqueued
     int64_t fuse_seed_max = 65536; // ... up to this many points (beyond, the redundant seed arithmetic of the four waves costs more than the launch)
+    bool fuse_head = true;         // ... and the cooperative forward kernel runs the head (GPE_FUSE_HEAD=0: k_head_pde): whole steps only,
+    int64_t fuse_head_max = 6144;  // up to this many points (measured: 43.2 vs 46.5 us at 4 000, equal at 6 000, 64.3 vs 62.9 us at 8 192)
+    bool fh_want = false;          // gpe_step / graph capture in progress: nobody reads the step sums between the passes
+    bool fh_now = false;           // the forward pass of this step left per-workgroup head sums in head_slots
+    double* head_slots = nullptr;  // [HEAD_SLOTS][4]
     UpdSnap* upd_snap = nullptr;   // multi-workgroup update (P >= UPD_MULTI_MIN): partial norms + snapshot of sums / optimiser state
     gpe_scalars *hist = nullptr, *last = nullptr;
     int cap = 65536;
@@ -549,9 +554,35 @@ static bool fwd_coop(gpe_engine* e, const Batch& b) {
     if (e->H == 128) return e->coop_fwd128;           // wide layers: the cooperative forward wins at every size (measured)
     return (b.n + 15) / 16 <= e->coop_fwd_max_tiles;
 }
+#define HEAD_SLOTS 512
+static bool seed_in_reverse(gpe_engine* e);
+// whole steps (gpe_step / gpe_run) of the small-batch class whose reverse kernel forms the seeds: the cooperative forward kernel runs
+// the head too, k_head_pde is not launched and the step sums are added in a fixed order
+static bool head_fusable(gpe_engine* e) {
+    return e->fuse_head && e->head_slots && e->H <= 64 && e->main.n <= e->fuse_head_max && fwd_coop(e, e->main) && seed_in_reverse(e) &&
+           fused_grid(e, e->main.n, 1, 2) <= HEAD_SLOTS;
+}
+static bool head_in_forward(gpe_engine* e) {
+    return e->fuse_head && e->fh_want && head_fusable(e);
+}
 template <int HH, int CC, int EE, int NO>
 static void launch_fcoop_no(gpe_engine* e, Batch& b, unsigned grid, size_t lds, int store) {
 #define CARGS e->nd, e->theta, e->Wpk, b.pts, b.stored, b.O, b.n, b.ld, store
+    if constexpr (HH <= 64 && NO == 1 && CC >= 3) {
+        if (e->fh_now && &b == &e->main) {
+            const HeadArgs ha{e->ph, e->base_norm, b.V, (const float* const*)e->orth_dev, e->bc_target, b.u, b.Hu, b.Ob, e->n_pde, b.ld, e->head_slots};
+            const size_t ldsh = lds + (size_t)CC * 16 * sizeof(float);
+            switch (e->nd.n_lin - 2) {
+                case 1: hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, 1, 1, true>), dim3(grid), dim3(HH * 4), ldsh, e->stream, CARGS, ha); break;
+                case 2: hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, 1, 2, true>), dim3(grid), dim3(HH * 4), ldsh, e->stream, CARGS, ha); break;
+                default: hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, 1, 3, true>), dim3(grid), dim3(HH * 4), ldsh, e->stream, CARGS, ha); break;
+            }
+            return;
+        }
+    }
+#undef CARGS
+    const HeadArgs nohead{};
+#define CARGS e->nd, e->theta, e->Wpk, b.pts, b.stored, b.O, b.n, b.ld, store, nohead
     switch (e->nd.n_lin - 2) {
         case 1: hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, NO, 1>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
         case 2: hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, NO, 2>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
@@ -682,7 +713,9 @@ static void launch_coop_no(gpe_engine* e, Batch& b, unsigned grid, size_t lds) {
         if constexpr (!(HH == 64 && CC == 5)) if (use_pipe(e, CC)) {       // (H = 64 in 3D: two workgroups' exchange buffers exceed the LDS)
             if constexpr (NO == 1 && CC >= 3) {
                 if (e->seedf_now && &b == &e->main) {       // small batch: the kernel forms the seeds itself (k_seed_pde was not launched)
-                    const SeedArgs sa{e->ph, b.V, b.u, b.Hu, (const double*)e->sums(), e->dsc(), e->n_pde};
+                    const SeedArgs sa{e->ph, b.V, b.u, b.Hu, (const double*)e->sums(), e->dsc(), e->n_pde,
+                                      e->fh_now ? (const double*)e->head_slots : nullptr, e->fh_now ? (int)fused_grid(e, b.n, 1, 2) : 0,
+                                      e->sums(), e->lsums()};
                     switch (e->nd.n_lin - 2) {
                         case 1: hipLaunchKernelGGL((f_backward_pipe<HH, CC, EE, 1, 1, true>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS, sa); break;
                         case 2: hipLaunchKernelGGL((f_backward_pipe<HH, CC, EE, 1, 2, true>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS, sa); break;
@@ -1125,6 +1158,9 @@ int gpe_active_kernels(gpe_engine* e, char* buf, size_t n) {
                                 (e->bwd_b6 && e->H <= 64) ? ",b6" : "");
         else if (kind == 2) snprintf(r, sizeof r, "f_backward<%d,%d,%d,%d,wlds,racc%d>", e->H, b.C, b.E, e->nd.n_out, maps > 3 ? 3 : maps);
         else snprintf(r, sizeof r, "f_backward<%d,%d,%d,%d,l2,%s>", e->H, b.C, b.E, e->nd.n_out, e->H > 64 ? "gacc" : "ldsacc");
+        // (whole steps, gpe_step / gpe_run: the split-phase protocol of the data-parallel driver keeps k_head_pde)
+        if (fc && head_fusable(e))
+            snprintf(f + strlen(f) - 1, sizeof f - strlen(f) + 1, ",head>");
     } else {
         const int W = e->nd.width[1];
         const bool m2 = e->gen_mfma && e->gen_mfma2 && W % 256 == 0, m1 = e->gen_mfma && W % 64 == 0;
@@ -1242,6 +1278,11 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
         e->fuse_seed = !(envf3 && atoi(envf3) == 0);
         const char* envf4 = getenv("GPE_FUSE_SEED_MAX");
         if (envf4) e->fuse_seed_max = atoll(envf4);
+        const char* envf5 = getenv("GPE_FUSE_HEAD");
+        e->fuse_head = !(envf5 && atoi(envf5) == 0);
+        const char* envf6 = getenv("GPE_FUSE_HEAD_MAX");
+        if (envf6) e->fuse_head_max = atoll(envf6);
+        if (ok && e->fuse_head) ok = alloc((void**)&e->head_slots, (size_t)HEAD_SLOTS * 4 * sizeof(double));
 
     }
     if (ok && e->path == GPE_PATH_FUSED) {
@@ -1377,7 +1418,7 @@ void gpe_destroy(gpe_engine* e) {
     free_batch(e->main); free_batch(e->bc); free_batch(e->sym); free_batch(e->aux); free_batch(e->mse);
     for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
     if (e->ext_exchange) { e->grad = nullptr; e->dbl = nullptr; }
-    void* ps[] = {e->theta, e->am, e->av, e->grad, e->dbl, e->od, e->hist, e->last, (void*)e->orth_dev, e->Wpk, e->WpkT, e->gslab, e->gslab_bc, e->grad_bc, (void*)e->upd_snap};
+    void* ps[] = {e->theta, e->am, e->av, e->grad, e->dbl, e->od, e->hist, e->last, (void*)e->orth_dev, e->Wpk, e->WpkT, e->gslab, e->gslab_bc, e->grad_bc, (void*)e->upd_snap, (void*)e->head_slots};
     for (void* p : ps) if (p) (void)hipFree(p);
     delete e;
 }
@@ -1596,8 +1637,9 @@ int gpe_step_begin(gpe_engine* e) {
     int rc;
     if ((rc = launch_begin(e))) return rc;
     if ((rc = bc_fork(e, true))) return rc;
-    if ((rc = mlp_forward(e, e->main, true))) return rc;
-    if ((rc = launch_head_pde(e))) return rc;
+    e->fh_now = head_in_forward(e);
+    if ((rc = mlp_forward(e, e->main, true))) { e->fh_now = false; return rc; }
+    if (!e->fh_now && (rc = launch_head_pde(e))) return rc;
     if (e->cfg.w_sym != 0.f) {
         if ((rc = mlp_forward(e, e->sym, true))) return rc;
         hipLaunchKernelGGL(k_head_sym, dim3(cdiv(e->n_pde, 256)), dim3(256), 0, e->stream, e->ph, e->sym.O, e->sums(),
@@ -1664,6 +1706,7 @@ int gpe_step_backward(gpe_engine* e) {
     if (!e->seedf_now && (rc = launch_seed_pde(e, nullptr, 1))) return rc;
     rc = mlp_backward(e, e->main, /*close=*/!with_sym);
     e->seedf_now = false;
+    e->fh_now = false;
     if (rc) return rc;
     if (with_sym) {
         hipLaunchKernelGGL(k_seed_sym, dim3(cdiv(e->n_pde, 256)), dim3(256), 0, e->stream, e->ph, e->sym.O, e->sym.Ob,
@@ -1986,7 +2029,11 @@ int gpe_read_history(gpe_engine* e, int64_t first, int64_t count, gpe_scalars* o
 
 int gpe_step(gpe_engine* e, gpe_scalars* out) {
     int rc;
-    if ((rc = gpe_step_begin(e))) return rc;
+    if (!e) return GPE_ERR_INVALID;
+    e->fh_want = true;                            // begin and backward are enqueued back to back: the head may ride in the forward kernel
+    rc = gpe_step_begin(e);
+    e->fh_want = false;
+    if (rc) return rc;
     if ((rc = gpe_step_backward(e))) return rc;
     if ((rc = gpe_step_update(e))) return rc;
     if (out) return gpe_read_scalars(e, out);
@@ -2027,7 +2074,10 @@ static int graph_build(gpe_engine* e) {
     hipGraph_t g = nullptr;
     int rc = GPE_OK;
     if (hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { e->stream = s0; return GPE_ERR_HIP; }
-    if (!(rc = gpe_step_begin(e)) && !(rc = gpe_step_backward(e))) rc = gpe_step_update(e);
+    e->fh_want = true;
+    rc = gpe_step_begin(e);
+    e->fh_want = false;
+    if (!rc && !(rc = gpe_step_backward(e))) rc = gpe_step_update(e);
     hipError_t st = hipStreamEndCapture(e->cap_stream, &g);
     e->stream = s0;
     e->phase = 0;

@@ -27,6 +27,7 @@
 #include "gpe_common.h"
 
 #include "gpe_mfma_util.h"
+#include "gpe_head.h"
 
 #ifndef GPE_FWD_WAVES
 #define GPE_FWD_WAVES 2      // waves per SIMD the forward kernel is compiled for (C <= 5)
@@ -738,17 +739,24 @@ __global__ __launch_bounds__((NHH > 0 ? 256 : (WLDS ? 512 : 256)), ((NHH > 0 || 
 // features 16w..16w+15 of every hidden layer from its register-resident rows of W_j; the activation-jet fragments are
 // all-gathered through a ping-pong LDS buffer (one barrier per layer), the output layer is reduced across the waves in LDS.
 // A tile's latency is ~NT times shorter than in f_forward: the kernel of choice when a batch has only a few tiles per wave.
-template <int H, int C, int E, int NOUT, int NHH>
+// HEADF (small batches of real psi without orthogonality / Riesz / symmetry terms, single-engine steps): the kernel also runs the head
+// of its tiles' rows -- u, H u, boundary seeds (head_point_real, gpe_head.h) -- and leaves ONE (num, den, bse) triple per workgroup in
+// ha.slots; k_head_pde is not launched, and the sums become reproducible bit for bit (no atomics: the reverse kernel adds the
+// triples in index order).
+template <int H, int C, int E, int NOUT, int NHH, bool HEADF = false>
 __global__ __launch_bounds__(H * 4, 2) void f_forward_coop(NetDesc nd, const float* __restrict__ theta,
                                                            const float* __restrict__ Wpk, Pts x,
                                                            float* __restrict__ stored, float* __restrict__ O, int64_t N,
-                                                           int64_t ld, int store_acts) {
+                                                           int64_t ld, int store_acts, HeadArgs ha) {
+    static_assert(!HEADF || NOUT == 1, "head in the forward kernel: real psi");
     constexpr int D = C - 1 - E, NT = H / 16, NTHR = 64 * NT;
     constexpr int L = NHH + 1;
     extern __shared__ __attribute__((aligned(16))) float lds_c[];
     float* w0s = lds_c;
     float* AB = w0s + ((small_count(nd, H) + 3) & ~3);          // [2][C][NT][256]
     float* OP = AB + 2 * C * NT * 256;                          // [NT][NOUT][C][16]
+    float* OF = OP + NT * NOUT * C * 16;                        // HEADF: [C][16] final output jets of the tile
+    double hnum = 0.0, hden = 0.0, hbse = 0.0;                  // HEADF: partial sums of this workgroup's rows (threads 0..15)
     const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4, w = threadIdx.x >> 6;
     const int dim = nd.dim;
     const float shift = nd.shift;
@@ -830,6 +838,31 @@ __global__ __launch_bounds__(H * 4, 2) void f_forward_coop(NetDesc nd, const flo
             for (int ww = 0; ww < NT; ++ww) v += OP[((ww * NOUT + o) * C + c) * 16 + pmi];
             const int64_t p = tile * 16 + pmi;
             if (p < N) O[((int64_t)c * NOUT + o) * ld + p] = v;
+            if constexpr (HEADF) OF[c * 16 + pmi] = v;
+        }
+        if constexpr (HEADF) {
+            __syncthreads();
+            if (threadIdx.x < 16 && valid) {                        // thread t = point t of the tile (its coordinates are in xv)
+                float Oj[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) Oj[c] = OF[c * 16 + threadIdx.x];
+                head_point_real<C, E>(ha, xv, pm, N, Oj, hnum, hden, hbse);
+            }
+        }
+    }
+    if constexpr (HEADF) {
+        if (threadIdx.x < 64) {
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) {
+                hnum += __shfl_down(hnum, o, 64);
+                hden += __shfl_down(hden, o, 64);
+                hbse += __shfl_down(hbse, o, 64);
+            }
+            if (threadIdx.x == 0) {
+                ha.slots[(size_t)blockIdx.x * 4 + 0] = hnum;
+                ha.slots[(size_t)blockIdx.x * 4 + 1] = hden;
+                ha.slots[(size_t)blockIdx.x * 4 + 2] = hbse;
+            }
         }
     }
 }
@@ -1225,6 +1258,31 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_pipe(NetDesc nd, const fl
 #pragma unroll
     for (int s2 = 0; s2 < 4; ++s2) ztr[s2] = 4 * (((4 * q + s2) ^ (m >> 2)) + 16 * (m >> 2)) + (m & 3);
 
+    float s_lam = 0.f, s_I = 0.f;
+    if constexpr (SEEDF) {
+        if (sa.slots) {                                   // the forward kernel left per-workgroup (num, den, bse): add them in index order
+            double* sd = reinterpret_cast<double*>(ZB);   // (scratch: the exchange buffers are zeroed right after)
+            for (int i = tix; i < sa.nslots * 3; i += NTHR) sd[i] = sa.slots[(size_t)(i / 3) * 4 + i % 3];
+            __syncthreads();
+            if (tix < 3) {
+                double t = 0.0;
+                for (int b = 0; b < sa.nslots; ++b) t += sd[b * 3 + tix];
+                sd[sa.nslots * 3 + tix] = t;
+            }
+            __syncthreads();
+            const double tn = sd[sa.nslots * 3], td = sd[sa.nslots * 3 + 1], tb = sd[sa.nslots * 3 + 2];
+            s_lam = (float)(tn / td);
+            s_I = (float)td * sa.ph.dx;
+            if (vb == 0 && tix == 0) {                    // ... and file the totals where k_update reads them (a separate boundary batch adds its own)
+                sa.sums_out[S_NUM] = tn; sa.sums_out[S_DEN] = td;
+                if (tb != 0.0) atomicAdd(&sa.lsums_out[LS_BC_SE2], tb);
+            }
+            __syncthreads();
+        } else {
+            s_lam = (float)(sa.sums[S_NUM] / sa.sums[S_DEN]);
+            s_I = (float)sa.sums[S_DEN] * sa.ph.dx;
+        }
+    }
     for (int i = tix; i < ((n_gsm + 3) & ~3) + 4 * H; i += NTHR) gsm[i] = 0.f;      // gsm and g0 are contiguous
     // exchange buffers start as zeros: the first interval's deferred product (no tile before it) then adds nothing -- no special case
     for (int i = tix; i < 4 * ZSZ / 4; i += NTHR) reinterpret_cast<f32x4*>(ZB)[i] = (f32x4)(0.f);
@@ -1232,8 +1290,6 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_pipe(NetDesc nd, const fl
     float xv[3] = {0.f, 0.f, 0.f};
     float ob[NOUT][C];
     double r2acc = 0.0;                                // SEEDF: sum of r^2 over this workgroup's collocation rows (wave 0, q = 0 lanes)
-    float s_lam = 0.f, s_I = 0.f;
-    if constexpr (SEEDF) { s_lam = (float)(sa.sums[S_NUM] / sa.sums[S_DEN]); s_I = (float)sa.sums[S_DEN] * sa.ph.dx; }
     auto load_point = [&](int64_t tile) {              // coordinates and output-jet adjoints of the lane's point
         const int64_t pm = tile * 16 + m;
         const bool valid = pm < N;

@@ -9,11 +9,11 @@
 
 // u-jets (value, first, second derivatives) of component o at point m from NN output jets.
 // bptr: device array of pointers; [0..3] orthogonality modes, [4..6] precomputed base phi, phi', phi''.
+// (U holds the raw NN output jets of the component on entry)
 template <int C, int E>
-GPE_DEV void load_u_jets(const Phys& ph, const float* __restrict__ O, int64_t ld, int64_t m, int o,
-                         const float* xv, float base_norm, const float* const* __restrict__ bptr, float* U /*[C]*/) {
+GPE_DEV void u_jets_from(const Phys& ph, int64_t m, const float* xv, float base_norm, const float* const* __restrict__ bptr, float* U /*[C]*/) {
 #pragma unroll
-    for (int c = 0; c < C; ++c) U[c] = ph.perturb_scale * O[((int64_t)c * ph.n_out + o) * ld + m];
+    for (int c = 0; c < C; ++c) U[c] = ph.perturb_scale * U[c];
     if constexpr (C == 3 && E == 1) {
         if (ph.envelope == GPE_ENV_SIN) {              // psi = o f : product rule on the jets
             float f, f1, f2;
@@ -30,6 +30,63 @@ GPE_DEV void load_u_jets(const Phys& ph, const float* __restrict__ O, int64_t ld
             U[0] += phi; U[1] += p1; U[2] += p2;
         }
     }
+}
+template <int C, int E>
+GPE_DEV void load_u_jets(const Phys& ph, const float* __restrict__ O, int64_t ld, int64_t m, int o,
+                         const float* xv, float base_norm, const float* const* __restrict__ bptr, float* U /*[C]*/) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) U[c] = O[((int64_t)c * ph.n_out + o) * ld + m];
+    u_jets_from<C, E>(ph, m, xv, base_norm, bptr, U);
+}
+
+// One row of a training batch of REAL psi without orthogonality / Riesz terms, from the raw NN output jets Oj[C] of the point -- what
+// k_head_pde does for such a row, as a function: the cooperative forward kernel of small batches runs it in its epilogue (HeadArgs)
+// and the head kernel is not launched.  Collocation row: u, H u to global memory, num += u Hu, den += u^2.  Boundary row riding in the
+// batch (m >= n_pde): e = base + s NN - target, bse += e^2, seeds straight to Ob.
+struct HeadArgs {
+    Phys ph; float base_norm;
+    const float* Vpre; const float* const* bptr; const float* bc_target;
+    float* u; float* Hu; float* Ob;                          // [ld] / [C][ld]
+    int64_t n_pde, ld;
+    double* slots;                                           // [gridDim.x][4]: this workgroup's (num, den, bse) partial sums
+};
+template <int C, int E>
+GPE_DEV void head_point_real(const HeadArgs& ha, const float* xv, int64_t m, int64_t N, const float* Oj, double& num, double& den, double& bse) {
+    constexpr int D = C - 1 - E;
+    const Phys& ph = ha.ph;
+    if (m >= ha.n_pde) {
+        const int64_t mb = m - ha.n_pde;
+        const float cnt = (float)((N - ha.n_pde) * ph.n_out);
+        float fenv = 1.0f;
+        if (ph.envelope == GPE_ENV_SIN) { float f1, f2; envelope_at(ph, xv[0], fenv, f1, f2); }
+        float e = ph.bc_nn_scale * fenv * Oj[0];
+        if (ph.base_mode >= 0 && ph.base_kind != GPE_BASE_PRECOMPUTED) {
+            float phi, p1, p2;
+            base_at(ph, xv[0], ha.base_norm, phi, p1, p2);
+            e += phi;
+        }
+        if (ha.bc_target) e -= ha.bc_target[mb * ph.n_out];
+        bse += (double)(e * e);
+        ha.Ob[m] = ph.w_bc * 2.0f / cnt * e * ph.bc_nn_scale * fenv * ph.inv_world;
+#pragma unroll
+        for (int c = 1; c < C; ++c) ha.Ob[(int64_t)c * ha.ld + m] = 0.f;
+        return;
+    }
+    const float V = potential_at(ph, xv, ha.Vpre, m);
+    float U[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) U[c] = Oj[c];
+    u_jets_from<C, E>(ph, m, xv, ha.base_norm, ha.bptr, U);
+    const float u = U[0];
+    float lap = 0.f;
+#pragma unroll
+    for (int j = 0; j < E; ++j) lap += U[1 + D + j];
+    const float inter = ph.abs_power ? ph.gamma * ipowf(fabsf(u), ph.p - 1) * u : ph.gamma * ipowf(u, ph.p);
+    const float Hu = -ph.kin * lap + V * u + inter;
+    ha.u[m] = u;
+    ha.Hu[m] = Hu;
+    num += (double)(u * Hu);
+    den += (double)(u * u);
 }
 
 // ---- phase 1: u, Hu per point; block partial sums into sums[] (double atomics) ---------------------

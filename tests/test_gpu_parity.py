@@ -562,12 +562,14 @@ def test_side_stream_and_graph_replay_change_nothing(kw, N):
 @pytest.mark.parametrize("kw,N,envs", [
     (dict(layers=[2, 64, 64, 64, 64, 1], gamma=50.0, dx=0.01), 4096,
      [{"GPE_COOP": "1", "GPE_COOP_FWD_MAX_TILES": "0"}, {"GPE_COOP": "1", "GPE_COOP_FWD_MAX_TILES": "1000000000"},
+      {"GPE_COOP": "1", "GPE_COOP_FWD_MAX_TILES": "1000000000", "GPE_FUSE_HEAD": "0"},   # head by k_head_pde instead of inside the forward kernel
       {"GPE_COOP": "1", "GPE_PIPE": "0", "GPE_COOP_FWD_MAX_TILES": "0"},          # two-barrier cooperative reverse kernel
       {"GPE_COOP": "1", "GPE_FUSE_SEED": "0", "GPE_COOP_FWD_MAX_TILES": "0"},     # seeds by k_seed_pde instead of inside the reverse kernel
       {"GPE_COOP": "0", "GPE_STAGE_MIN_TILES": "0"}, {"GPE_COOP": "0", "GPE_STAGE_MIN_TILES": "1000000000"},
       {"GPE_COOP": "0", "GPE_STAGE_MIN_TILES": "0", "GPE_RACC": "0"}, {"GPE_COOP": "0", "GPE_WLDS": "0"}]),
     (dict(layers=[1, 32, 32, 32, 1], gamma=5.0, base_mode=0, dx=0.01), 1000,
-     [{"GPE_COOP": "1"}, {"GPE_COOP": "1", "GPE_PIPE": "0"}, {"GPE_COOP": "1", "GPE_FUSE_SEED": "0"}, {"GPE_COOP": "0", "GPE_STAGE_MIN_TILES": "0"},
+     [{"GPE_COOP": "1"}, {"GPE_COOP": "1", "GPE_PIPE": "0"}, {"GPE_COOP": "1", "GPE_FUSE_SEED": "0"}, {"GPE_COOP": "1", "GPE_FUSE_HEAD": "0"},
+      {"GPE_COOP": "0", "GPE_STAGE_MIN_TILES": "0"},
       {"GPE_COOP": "0", "GPE_STAGE_MIN_TILES": "1000000000"}]),
     (dict(layers=[2, 128, 128, 128, 1], gamma=50.0, dx=0.01), 777,
      [{"GPE_WIDE": "0", "GPE_COOP128": "1", "GPE_COOP_FWD128": "1"}, {"GPE_WIDE": "0", "GPE_COOP128": "0", "GPE_COOP_FWD128": "0"},
@@ -606,7 +608,7 @@ def test_kernel_variants_agree(kw, N, envs):
     # every row ran a different kernel pair -- unless the suite itself runs under a forced switch (e.g. GPE_FWD_B6=1 GPE_BWD_B6=1 to
     # put the split-bf16 kernels through every test), which makes some rows coincide: then at least two distinct pairs
     import os
-    forced = [k for k in ("GPE_FWD_B6", "GPE_BWD_B6", "GPE_PIPE", "GPE_COOP", "GPE_WIDE", "GPE_COOP_FWD_MAX_TILES", "GPE_STAGE_MIN_TILES", "GPE_FUSE_SEED")
+    forced = [k for k in ("GPE_FWD_B6", "GPE_BWD_B6", "GPE_PIPE", "GPE_COOP", "GPE_WIDE", "GPE_COOP_FWD_MAX_TILES", "GPE_STAGE_MIN_TILES", "GPE_FUSE_SEED", "GPE_FUSE_HEAD")
               if k in os.environ]
     if forced:
         assert len(seen) >= 2, f"forced {forced}: switches selected only {sorted(seen)}"
