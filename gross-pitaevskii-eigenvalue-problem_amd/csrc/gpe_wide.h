@@ -302,10 +302,17 @@ __global__ __launch_bounds__(512, 2) void w_bwd_out(NetDesc nd, const float* __r
 
 #undef W_TRACE_K
 #define W_TRACE_K 1
+#define W_MAP_PIPE(H, C) ((H) == 128 && (C) <= 4)
+#ifndef GPE_WIDE_STAGGER
+#define GPE_WIDE_STAGGER 0    // w_bwd_map, one-barrier form: 1 = waves 4..7 run the deferred products BEFORE the adjoint phase (measured: 0.705 vs 0.735)
+#endif
+#ifndef GPE_WIDE_PRIO_ACT
+#define GPE_WIDE_PRIO_ACT 0   // w_bwd_map: > 0 raises the wave's priority over its activation block, < 0 over its product phases
+#endif
 // ---- reverse, one hidden->hidden map ------------------------------------------------------------------------------------------
 // Zin = zbar_j, Zout = zbar_{j-1}: [tile][C][NT][256].  FIRST (j == 1): layer j-1 = 0 is recomputed from x, its gradients
 // (dW_0, db_0) are formed here and nothing is written to Zout.
-// LDS: gb[H] (db_j) | g0[4][H] | w0s | ZB[C][NT][256] | XT[C][8][F_TILE] (before the adjoint phase: the waves' transposition scratch)
+// LDS: gb[H] (db_j) | g0[4][H] | w0s | ZB[C][NT][256] (fragments at a swizzled slot) | XT[C][8][F_TILE]; H = 128 with C <= 4: two of each
 // TOP = n_out (1 or 2) for the launch of the topmost map j = L-1, 0 otherwise: there zbar_j is not read from HBM but formed
 // from the seeds Ob and the stored activations of the last hidden layer (what w_bwd_out does as a kernel of its own), and
 // dW_out / db_out are accumulated here -- one launch and one HBM round trip of the adjoint jets fewer.
@@ -323,10 +330,11 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
     float* g0 = gb + H;
     float* go = g0 + 4 * H;                                      // [2][H] dW_out | [4] db_out (TOP)
     float* w0s = go + 2 * H + 4;
+    constexpr bool PIPE = W_MAP_PIPE(H, C);                       // both exchange buffers doubled, one barrier per tile (below)
+    constexpr int ZSZ = C * NT * 256, XSZ = C * KTL * F_TILE;
     float* ZB = w0s + ((small_count(nd, H) + 3) & ~3);
-    float* XT = ZB + C * NT * 256;
+    float* XT = ZB + (PIPE ? 2 : 1) * ZSZ;
     const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4, w = threadIdx.x >> 6;
-    float* TT = XT + w * (C * F_TILE);
     int h, g;
     w_block_role(blockIdx.x, G, NSPLIT, h, g);
     const int L = nd.n_lin - 1;
@@ -335,6 +343,8 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
     const int64_t ntiles = (N + 15) >> 4;
     const int ktile = h * KTL + w;                               // this wave's feature tile of layer j-1
     for (int i = threadIdx.x; i < 7 * H + 4; i += NTHR) gb[i] = 0.f; // gb, g0 and go are contiguous
+    if constexpr (PIPE)
+        for (int i = threadIdx.x; i < (2 * ZSZ + 2 * XSZ) / 4; i += NTHR) reinterpret_cast<f32x4*>(ZB)[i] = (f32x4)(0.f);
     if constexpr (FIRST || TOP > 0) stage_layer0<H>(w0s, theta, nd, NTHR);
     const float* Wo = w0s + (4 + L - 1) * H;
     const float* wmap = WpkT + (size_t)(j - 1) * H * H;
@@ -384,23 +394,16 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
             for (int k = 0; k < 3; ++k) if (k < dim) xv[k] = pts_at(x, pl, dim, k);
         }
     };
-    if (g < ntiles) issue_loads(g);
+    // z fragments live in ZB at a swizzled slot: the B-operand reads (every wave, all of ZB) and the TRANSPOSED reads of the wave's own
+    // rows (A operands of the weight-gradient products: feature on lane) are both conflict-free, and no transposition scratch is needed
+    const int zfrag = 4 * ((m ^ q) + 16 * q);
+    int ztr[4];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) ztr[s2] = 4 * (((4 * q + s2) ^ (m >> 2)) + 16 * (m >> 2)) + (m & 3);
     WSTAMP_INIT;
-
-    for (int64_t tile = g; tile < ntiles; tile += G) {
-        WSTAMP_ITER;
-        asm volatile("" : "+s"(wofs));
-        f32x4 st[C];
-        if constexpr (FIRST) layer0_st<H, C, E>(w0s, xv, ktile, q, st);
-        else {
-            const float* sp = stored + ((((size_t)tile * (L - 1) + (j - 2)) * C) * NT + ktile) * 256 + lane * 4;
-#pragma unroll
-            for (int c = 0; c < C; ++c) st[c] = *reinterpret_cast<const f32x4*>(sp + (size_t)c * NT * 256);
-        }
-        const float xk[3] = {xv[0], xv[1], xv[2]};             // this tile's coordinates (xv is overwritten by the prefetch)
-        f32x4 wn[W_KCB];
-#pragma unroll
-        for (int i = 0; i < W_KCB; ++i) wn[i] = load_w(i);
+    // zbar_j of a tile, own rows, into a z buffer.  TOP: formed here from the seeds and the stored activations of the last hidden layer
+    // (dW_out / db_out on the way); otherwise it is what issue_loads fetched.
+    auto publish = [&](float* zbuf) {
         if constexpr (TOP > 0) {                                 // output layer: dW_out, db_out, zbar_{L-1} = act-adjoint(W_out^T Ob), own rows
 #pragma unroll
             for (int rt = 0; rt < RTZ; ++rt) {
@@ -444,27 +447,27 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
                 }
             }
         }
-        WSTAMP(0);
-        __syncthreads();                                         // previous tile: XT (products) and ZB (adjoint) are no longer read
-        WSTAMP(1);
-        f32x4 zt[RTZ][C];
 #pragma unroll
-        for (int rt = 0; rt < RTZ; ++rt) {
+        for (int rt = 0; rt < RTZ; ++rt)
 #pragma unroll
-            for (int c = 0; c < C; ++c) *reinterpret_cast<f32x4*>(&ZB[(c * NT + w * RTZ + rt) * 256 + lane * 4]) = zf[rt][c];
-            tiles_transpose<C>(zf[rt], zt[rt], TT, m, q);          // feature-on-lane copy for the weight-gradient products
-            if (h == 0) {                                        // bias gradient of map j: row sums of the value channel
-                float s = (zt[rt][0][0] + zt[rt][0][1]) + (zt[rt][0][2] + zt[rt][0][3]);
-                s += __shfl_xor(s, 16, 64);
-                s += __shfl_xor(s, 32, 64);
-                dbacc[rt] += s;
-            }
+            for (int c = 0; c < C; ++c) *reinterpret_cast<f32x4*>(&zbuf[(c * NT + w * RTZ + rt) * 256 + zfrag]) = zf[rt][c];
+    };
+    f32x4 st[C];
+    f32x4 wn[W_KCB];
+    float xk[3] = {0.f, 0.f, 0.f};
+    auto load_st = [&](int64_t t) {
+        if constexpr (!FIRST) {
+            const float* sp = stored + ((((size_t)t * (L - 1) + (j - 2)) * C) * NT + ktile) * 256 + lane * 4;
+#pragma unroll
+            for (int c = 0; c < C; ++c) st[c] = *reinterpret_cast<const f32x4*>(sp + (size_t)c * NT * 256);
         }
-        WSTAMP(2);
-        __syncthreads();                                         // ZB complete; the scratch (= XT) may be overwritten from here on
-        WSTAMP(3);
-        // abar (own feature tile of layer j-1) = sum_nt W_j^T[ktile, nt] zbar_j[nt] : C independent accumulator chains
-        f32x4 acc[C];
+#pragma unroll
+        for (int i = 0; i < W_KCB; ++i) wn[i] = load_w(i);
+    };
+    // adjoint phase of a tile: abar (own feature tile of layer j-1) = sum_nt W_j^T[ktile, nt] zbar_j[nt] from `zbuf` (all rows), activation
+    // adjoint -> zbar_{j-1} (HBM; FIRST: layer-0 gradients), X_{j-1} of the own feature tile -> `xbuf`
+    auto adjoint_phase = [&](int64_t tile, const float* zbuf, float* xbuf) {
+        f32x4 acc[C];                                            // C independent accumulator chains
 #pragma unroll
         for (int c = 0; c < C; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -481,7 +484,7 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
             for (int i = 0; i < W_KCB; ++i) {
                 f32x4 bf[C];
 #pragma unroll
-                for (int c = 0; c < C; ++c) bf[c] = *reinterpret_cast<const f32x4*>(&ZB[(c * NT + n0 + i) * 256 + lane * 4]);
+                for (int c = 0; c < C; ++c) bf[c] = *reinterpret_cast<const f32x4*>(&zbuf[(c * NT + n0 + i) * 256 + zfrag]);
 #pragma unroll
                 for (int s2 = 0; s2 < 4; ++s2)
 #pragma unroll
@@ -490,6 +493,7 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
             }
         }
         WSTAMP(4);
+        if constexpr (GPE_WIDE_PRIO_ACT != 0) __builtin_amdgcn_s_setprio(GPE_WIDE_PRIO_ACT > 0 ? GPE_WIDE_PRIO_ACT : 0);
         // recompute X of layer j-1 (own tile), activation adjoint -> zbar_{j-1}
         f32x4 xa[C], zb[C];
         act_from_stored<D, E>(st[0], st + 1, st + 1 + D, shift, xa);
@@ -517,13 +521,27 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
 #pragma unroll
         for (int c = 0; c < C; ++c)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) XT[(c * KTL + w) * F_TILE + (4 * q + r) * F_PITCH + tr_wcol(m, q)] = xa[c][r];
-        if (tile + G < ntiles) issue_loads(tile + G);            // next tile's loads: in flight behind the products below
-        __builtin_amdgcn_sched_barrier(0);
-        WSTAMP(5);
-        __syncthreads();
-        WSTAMP(6);
-        // dW_j[own rows][columns of this half] += Zbar^T X : RTZ * 4 independent accumulator chains per chunk
+            for (int r = 0; r < 4; ++r) xbuf[(c * KTL + w) * F_TILE + (4 * q + r) * F_PITCH + tr_wcol(m, q)] = xa[c][r];
+        if constexpr (GPE_WIDE_PRIO_ACT != 0) __builtin_amdgcn_s_setprio(GPE_WIDE_PRIO_ACT > 0 ? 0 : -GPE_WIDE_PRIO_ACT);
+    };
+    // weight-gradient phase: dW_j[own rows][columns of this half] += Zbar^T X -- the wave's own rows of `zbuf` re-read feature-on-lane,
+    // X_{j-1} (all feature tiles of this half) from `xbuf`: RTZ * 4 independent accumulator chains per chunk
+    auto product_phase = [&](const float* zbuf, const float* xbuf) {
+        f32x4 zt[RTZ][C];
+#pragma unroll
+        for (int rt = 0; rt < RTZ; ++rt) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float* zo = &zbuf[(c * NT + w * RTZ + rt) * 256];
+                zt[rt][c] = (f32x4){zo[ztr[0]], zo[ztr[1]], zo[ztr[2]], zo[ztr[3]]};
+            }
+            if (h == 0) {                                        // bias gradient of map j: row sums of the value channel
+                float s = (zt[rt][0][0] + zt[rt][0][1]) + (zt[rt][0][2] + zt[rt][0][3]);
+                s += __shfl_xor(s, 16, 64);
+                s += __shfl_xor(s, 32, 64);
+                dbacc[rt] += s;
+            }
+        }
 #pragma unroll
         for (int k0 = 0; k0 < KTL; k0 += 4)
 #pragma unroll
@@ -531,7 +549,7 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
                 f32x4 xf[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    xf[i] = *reinterpret_cast<const f32x4*>(&XT[(c * KTL + k0 + i) * F_TILE + tr_roff(m, q)]);
+                    xf[i] = *reinterpret_cast<const f32x4*>(&xbuf[(c * KTL + k0 + i) * F_TILE + tr_roff(m, q)]);
 #pragma unroll
                 for (int s2 = 0; s2 < 4; ++s2)
 #pragma unroll
@@ -540,7 +558,79 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
                         for (int rt = 0; rt < RTZ; ++rt)
                             dwacc[rt][k0 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(zt[rt][c][s2], xf[i][s2], dwacc[rt][k0 + i], 0, 0, 0);
             }
-        WSTAMP(7);
+    };
+    if (g < ntiles) {
+        issue_loads(g);
+        if constexpr (PIPE) load_st(g);
+        publish(ZB);
+    }
+    if constexpr (PIPE) {
+        // H = 128, C <= 4: one workgroup per CU anyway, so both exchange buffers are doubled (137 KB) and the weight-gradient products of
+        // a tile are DEFERRED behind the adjoint phase of the next one -- ONE barrier per tile, and between two barriers every wave has
+        // adjoint products, activation arithmetic and weight-gradient products in a row: the two waves of a SIMD fall out of step by
+        // themselves and one's VALU work runs under the other's matrix work.  (The second pair of buffers starts as zeros: the first
+        // interval's deferred products add nothing.)
+        float *zr = ZB, *zw = ZB + ZSZ, *xw = XT, *xr = XT + XSZ;
+        const int wu = __builtin_amdgcn_readfirstlane(w);
+        for (int64_t tile = g; tile < ntiles; tile += G) {
+            WSTAMP_ITER;
+            asm volatile("" : "+s"(wofs));
+            if constexpr (FIRST) layer0_st<H, C, E>(w0s, xv, ktile, q, st);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) xk[k] = xv[k];           // this tile's coordinates (xv is overwritten by the prefetch)
+            WSTAMP(0);
+            __syncthreads();                                     // zr (this tile's zbar_j) and xr (the previous tile's X) complete
+            WSTAMP(1);
+            const bool more = tile + G < ntiles;
+            if (GPE_WIDE_STAGGER && wu >= W_NW / 2) {
+                // the SIMD partners (waves w and w + 4) take the two product phases of the interval in opposite order: one's
+                // activation arithmetic then runs under the other's matrix work instead of both reaching it together
+                if (more) issue_loads(tile + G);
+                __builtin_amdgcn_sched_barrier(0);
+                product_phase(zw, xr);
+                WSTAMP(7);
+                adjoint_phase(tile, zr, xw);
+                if (more) load_st(tile + G);
+                WSTAMP(5);
+            } else {
+                adjoint_phase(tile, zr, xw);
+                if (more) { issue_loads(tile + G); load_st(tile + G); }  // in flight behind the products below
+                __builtin_amdgcn_sched_barrier(0);
+                WSTAMP(5);
+                product_phase(zw, xr);                           // previous tile: own rows of zw, all of xr
+                WSTAMP(7);
+            }
+            if (more) publish(zw);                               // next tile's zbar_j over the rows just read
+            float* t0 = zr; zr = zw; zw = t0;
+            t0 = xr; xr = xw; xw = t0;
+        }
+        __syncthreads();
+        product_phase(zw, xr);                                   // the last tile's products (zeros if this workgroup had no tile)
+    } else {
+        // Two barriers per tile.  After X: ZB holds zbar_j of the tile (all rows) and XT is free.  After Y: XT holds X_{j-1} of the tile and
+        // nobody reads ZB any more -- so the weight-gradient products (own rows of ZB re-read transposed, XT) are followed by the NEXT
+        // tile's rows going into ZB, and the barrier at the loop top closes both.
+        for (int64_t tile = g; tile < ntiles; tile += G) {
+            WSTAMP_ITER;
+            asm volatile("" : "+s"(wofs));
+            if constexpr (FIRST) layer0_st<H, C, E>(w0s, xv, ktile, q, st);
+            load_st(tile);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) xk[k] = xv[k];           // this tile's coordinates (xv is overwritten by the prefetch)
+            WSTAMP(0);
+            __syncthreads();                                     // X: ZB complete; the previous tile's products no longer read XT
+            WSTAMP(1);
+            adjoint_phase(tile, ZB, XT);
+            const bool more = tile + G < ntiles;
+            if (more) issue_loads(tile + G);                     // next tile's loads: in flight behind the products below
+            __builtin_amdgcn_sched_barrier(0);
+            WSTAMP(5);
+            __syncthreads();                                     // Y: XT complete; ZB is no longer read by the adjoint products
+            WSTAMP(6);
+            product_phase(ZB, XT);
+            WSTAMP(7);
+            if (more) publish(ZB);                               // own rows of the next tile's zbar_j (the reads above came first)
+        }
     }
     WSTAMP_FLUSH(8);
     // ---- slab: this workgroup's block of dW_j, db_j (h == 0), layer-0 gradients of its features (FIRST) ------------------------

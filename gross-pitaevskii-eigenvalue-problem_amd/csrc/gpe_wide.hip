@@ -79,7 +79,7 @@ static void launch_bwd(const WideCall& a) {
     const int L = a.nd.n_lin - 1;
     const int no = a.nd.n_out;
     const size_t lds_o = ((size_t)((no * HH + no + 3) & ~3) + small4(a.nd, HH)) * sizeof(float);
-    const size_t lds_m = ((size_t)7 * HH + 4 + small4(a.nd, HH) + (size_t)CC * NT * 256 + (size_t)CC * W_NW * F_TILE) * sizeof(float);
+    const size_t lds_m = ((size_t)7 * HH + 4 + small4(a.nd, HH) + (W_MAP_PIPE(HH, CC) ? 2 : 1) * ((size_t)CC * NT * 256 + (size_t)CC * W_NW * F_TILE)) * sizeof(float);
     float* zcur = a.Z0;
     float* znext = a.Z1;
     const char* envt = getenv("GPE_WIDE_TOP");                 // 0: the output layer as a launch of its own (w_bwd_out)

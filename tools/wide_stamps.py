@@ -20,7 +20,10 @@ eng.run(5); eng.synchronize()
 rc = eng.lib.gpe_debug_read_wide_stamps(out)
 v = np.array(list(out), dtype=np.float64)
 names_f = ["epilogue+stores->top", "barrier1 wait", "AB write+barrier2", "MFMA loop", "-", "-", "-", "-"]
-names_b = ["top (st,w loads)", "barrier0 wait", "ZB write+transposes", "barrier1 wait", "adjoint MFMA", "act+Zout+XT+prefetch", "barrier2 wait", "dW MFMA"]
+# w_bwd_map since round 3 (stamps 2, 3 unused): next tile's rows into ZB + loop top | barrier | adjoint products | activation adjoint,
+# Zout, XT, prefetch | second barrier (single-buffer form only) | weight-gradient products
+names_b = ["publish + top (st,w loads)", "barrier wait", "(r02: ZB write+transposes)", "(r02: barrier1 wait)", "adjoint MFMA", "act+Zout+XT+prefetch",
+           "second barrier wait", "dW MFMA"]
 print("rc", rc)
 for nm, blk in (("w_forward", v[:8]), ("w_bwd_map", v[8:])):
     tot = blk.sum()
