@@ -284,6 +284,8 @@ struct SeedArgs {
     // of the reverse kernel adds the triples in index order (deterministic), workgroup 0 also files the totals for the update kernel
     const double* slots; int nslots;
     double* sums_out; double* lsums_out;
+    // f_backward_pipe, every variant: > 0 = the tiles of a CU's workgroup pair are split unevenly (share of the first-dispatched one, / 1024)
+    int old_share_q10;
 };
 
 // block-wide sum of a double over 256 threads -> valid in thread 0

@@ -355,6 +355,9 @@ struct gpe_engine {
     bool fuse_seed = true;         // small batches: the pipelined reverse kernel forms the seeds itself (GPE_FUSE_SEED=0: k_seed_pde)
     bool seedf_now = false;        // ... for the reverse pass being enqueued
     int64_t fuse_seed_max = 65536; // ... up to this many points (beyond, the redundant seed arithmetic of the four waves costs more than the launch)
+    int fwd_share = 640;           // f_forward: the same for its waves (GPE_FWD_SHARE; measured flat between 608 and 672: NS step 2.703 -> 2.688 ms)
+    int pipe_share = 576;          // f_backward_pipe: share (/1024) of a CU's tiles for its first-dispatched workgroup; 0 = even (GPE_PIPE_SHARE;
+                                   // NS reverse kernel 1.741 ms even, 1.727 / 1.719 / 1.715 / 1.730 / 1.741 ms at 544 / 576 / 592 / 608 / 640)
     bool fuse_head = true;         // ... and the cooperative forward kernel runs the head (GPE_FUSE_HEAD=0: k_head_pde): whole steps only,
     int64_t fuse_head_max = 6144;  // up to this many points (measured: 43.2 vs 46.5 us at 4 000, equal at 6 000, 64.3 vs 62.9 us at 8 192)
     bool fh_want = false;          // gpe_step / graph capture in progress: nobody reads the step sums between the passes
@@ -614,8 +617,10 @@ static void launch_f_forward(gpe_engine* e, Batch& b, unsigned grid, int store) 
             return;
         }
     }
+    // large batches on two workgroups per CU: uneven split of each CU's tiles between its two workgroups (GPE_FWD_SHARE, / 1024)
+    const int fshare = (e->fwd_share > 0 && grid == (unsigned)(2 * e->num_cu) && (b.n + 15) / 16 >= 64 * (int64_t)grid) ? e->fwd_share : 0;
     if constexpr (HH > 64) {
-        F_LAUNCH(f_forward, HH, CC, EE, false, grid, 256, fused_fwd_lds(e, false), e->nd, e->theta, e->Wpk, b.pts, b.stored, b.O, b.n, b.ld, store);
+        F_LAUNCH(f_forward, HH, CC, EE, false, grid, 256, fused_fwd_lds(e, false), e->nd, e->theta, e->Wpk, b.pts, b.stored, b.O, b.n, b.ld, store, fshare);
         return;
     }
     if constexpr (HH <= 64) {
@@ -642,9 +647,9 @@ static void launch_f_forward(gpe_engine* e, Batch& b, unsigned grid, int store) 
         }
     }
     if (e->fwd_wlds && staged_batch(e, b))
-        F_LAUNCH(f_forward, HH, CC, EE, true, grid, 256, fused_fwd_lds(e, true), e->nd, e->theta, e->Wpk, b.pts, b.stored, b.O, b.n, b.ld, store);
+        F_LAUNCH(f_forward, HH, CC, EE, true, grid, 256, fused_fwd_lds(e, true), e->nd, e->theta, e->Wpk, b.pts, b.stored, b.O, b.n, b.ld, store, fshare);
     else
-        F_LAUNCH(f_forward, HH, CC, EE, false, grid, 256, fused_fwd_lds(e, false), e->nd, e->theta, e->Wpk, b.pts, b.stored, b.O, b.n, b.ld, store);
+        F_LAUNCH(f_forward, HH, CC, EE, false, grid, 256, fused_fwd_lds(e, false), e->nd, e->theta, e->Wpk, b.pts, b.stored, b.O, b.n, b.ld, store, fshare);
 }
 // reverse-kernel variant for one batch: 3 = cooperative (a workgroup per tile, a wave per 16-feature slice),
 // 2 = weight gradients in registers (1 wave/SIMD),
@@ -715,7 +720,7 @@ static void launch_coop_no(gpe_engine* e, Batch& b, unsigned grid, size_t lds) {
                 if (e->seedf_now && &b == &e->main) {       // small batch: the kernel forms the seeds itself (k_seed_pde was not launched)
                     const SeedArgs sa{e->ph, b.V, b.u, b.Hu, (const double*)e->sums(), e->dsc(), e->n_pde,
                                       e->fh_now ? (const double*)e->head_slots : nullptr, e->fh_now ? (int)fused_grid(e, b.n, 1, 2) : 0,
-                                      e->sums(), e->lsums()};
+                                      e->sums(), e->lsums(), 0};
                     switch (e->nd.n_lin - 2) {
                         case 1: hipLaunchKernelGGL((f_backward_pipe<HH, CC, EE, 1, 1, true>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS, sa); break;
                         case 2: hipLaunchKernelGGL((f_backward_pipe<HH, CC, EE, 1, 2, true>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS, sa); break;
@@ -724,7 +729,9 @@ static void launch_coop_no(gpe_engine* e, Batch& b, unsigned grid, size_t lds) {
                     return;
                 }
             }
-            const SeedArgs none{};
+            SeedArgs none{};
+            // large batches on two workgroups per CU: uneven split of each CU's tiles between its two workgroups (GPE_PIPE_SHARE, / 1024)
+            if (e->pipe_share > 0 && grid == (unsigned)(2 * e->num_cu) && (b.n + 15) / 16 >= 16 * (int64_t)grid) none.old_share_q10 = e->pipe_share;
             switch (e->nd.n_lin - 2) {
                 case 1: hipLaunchKernelGGL((f_backward_pipe<HH, CC, EE, NO, 1>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS, none); break;
                 case 2: hipLaunchKernelGGL((f_backward_pipe<HH, CC, EE, NO, 2>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS, none); break;
@@ -1278,6 +1285,10 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
         e->fuse_seed = !(envf3 && atoi(envf3) == 0);
         const char* envf4 = getenv("GPE_FUSE_SEED_MAX");
         if (envf4) e->fuse_seed_max = atoll(envf4);
+        const char* envps = getenv("GPE_PIPE_SHARE");
+        if (envps) e->pipe_share = atoi(envps);
+        const char* envfs = getenv("GPE_FWD_SHARE");
+        if (envfs) e->fwd_share = atoi(envfs);
         const char* envf5 = getenv("GPE_FUSE_HEAD");
         e->fuse_head = !(envf5 && atoi(envf5) == 0);
         const char* envf6 = getenv("GPE_FUSE_HEAD_MAX");

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256, ((C <= 5 && H <= 64) ? GPE_FWD_WAVES : 1)) voi
                                                                  const float* __restrict__ Wpk,
                                                                  Pts x, float* __restrict__ stored,
                                                                  float* __restrict__ O, int64_t N, int64_t ld,
-                                                                 int store_acts) {
+                                                                 int store_acts, int old_share_q10) {
     constexpr int D = C - 1 - E, NT = H / 16, NF = NT * 4;
     const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4;
     const unsigned lane4 = (unsigned)lane * 4u;
@@ -142,18 +142,30 @@ __global__ __launch_bounds__(256, ((C <= 5 && H <= 64) ? GPE_FWD_WAVES : 1)) voi
     __syncthreads();
 
     // point coordinates of the first tile; inside the loop the NEXT tile's are requested before this tile's math
+    // tiles of this wave: wave0, wave0 + nwaves, ... -- or, with old_share_q10 set (large batches on two workgroups per CU: workgroups
+    // b and b + G/2 share a CU, and the waves of the first-dispatched one win every arbitration), the tiles of such a pair of waves split
+    // unevenly so that both finish together (the same device as f_backward_pipe's, SeedArgs::old_share_q10)
+    int64_t tile0 = wave0, tstep = nwaves, tend = ntiles;
+    if (old_share_q10 > 0 && (gridDim.x & 1) == 0) {
+        const int64_t half = nwaves >> 1, p = wave0 % half;
+        const int64_t cnt = p < ntiles ? (ntiles - p + half - 1) / half : 0;
+        const int64_t n_old = (cnt * old_share_q10 + 512) >> 10;
+        tstep = half;
+        if (wave0 < half) { tile0 = p; tend = p + n_old * half < ntiles ? p + n_old * half : ntiles; }
+        else tile0 = p + n_old * half;
+    }
     float xn[3] = {0.f, 0.f, 0.f};
-    if (wave0 < ntiles) {
-        const int64_t p0 = min(wave0 * 16 + m, N - 1);
+    if (tile0 < tend) {
+        const int64_t p0 = min(tile0 * 16 + m, N - 1);
 #pragma unroll
         for (int k = 0; k < 3; ++k) if (k < dim) xn[k] = pts_at(x, p0, dim, k);
     }
-    for (int64_t tile = wave0; tile < ntiles; tile += nwaves) {
+    for (int64_t tile = tile0; tile < tend; tile += tstep) {
         const int64_t pm = tile * 16 + m;
         const bool valid = pm < N;
         float xv[3] = {xn[0], xn[1], xn[2]};
-        if (tile + nwaves < ntiles) {
-            const int64_t pn = min((tile + nwaves) * 16 + m, N - 1);
+        if (tile + tstep < tend) {
+            const int64_t pn = min((tile + tstep) * 16 + m, N - 1);
 #pragma unroll
             for (int k = 0; k < 3; ++k) if (k < dim) xn[k] = pts_at(x, pn, dim, k);
         }
@@ -1343,8 +1355,18 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_pipe(NetDesc nd, const fl
     for (int o = 0; o < NOUT; ++o) { gwoacc[o] = (f32x4)(0.f); gboacc[o] = 0.f; }
     // the first tile's point data and top-layer stored jets are requested here, beside the weight fragments (one L2 / HBM round trip
     // instead of two before the first product -- a workgroup of a 4 000-point batch has ONE tile)
-    int64_t tile = vb;
-    const int64_t tend = ntiles;
+    // tiles of this workgroup: vb, vb + G, ... -- or, with sa.old_share_q10 set (large batches, grid = two workgroups per CU: b and b + G/2
+    // share a CU and the first-dispatched one wins every arbitration, 27 k against 37 k cycles per tile), the tiles p, p + G/2, ... of the
+    // PAIR split so that both finish together: the older workgroup takes the first old_share_q10 / 1024 of them
+    int64_t tile = vb, tstep = nvb, tend = ntiles;
+    if (sa.old_share_q10 > 0 && (nvb & 1) == 0) {
+        const int64_t half = nvb >> 1, p = vb % half;
+        const int64_t cnt = p < ntiles ? (ntiles - p + half - 1) / half : 0;
+        const int64_t n_old = (cnt * sa.old_share_q10 + 512) >> 10;
+        tstep = half;
+        if (vb < half) { tile = p; tend = p + n_old * half < ntiles ? p + n_old * half : ntiles; }
+        else tile = p + n_old * half;
+    }
     f32x4 stl0[C];
     if (tile < tend) {
         load_point(tile);
@@ -1432,8 +1454,8 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_pipe(NetDesc nd, const fl
         g_trace[(vb * 4 + w) * 32 + 25] = st_last;       // tile loop entered
     }
 #endif
-    for (; tile < tend; tile += nvb) {
-        const bool have_next = tile + nvb < tend;
+    for (; tile < tend; tile += tstep) {
+        const bool have_next = tile + tstep < tend;
         float xv_t[3] = {xv[0], xv[1], xv[2]};         // this tile's coordinates (layer 0 recompute, layer-0 gradients)
 #ifdef GPE_STAMP
         ++it;
@@ -1449,8 +1471,8 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_pipe(NetDesc nd, const fl
             __syncthreads();
             PSTAMP(0, 4 * (NHH - j) + 1);
             if (j == 1 && have_next && PREF) {
-                load_point(tile + nvb);
-                if constexpr (L - 1 >= 1) load_st(tile + nvb, L - 1, stn);
+                load_point(tile + tstep);
+                if constexpr (L - 1 >= 1) load_st(tile + tstep, L - 1, stn);
             }
             __builtin_amdgcn_s_setprio(GPE_COOP_PRIO);
             // abar (own slice) = sum_nt W_j^T[slice, nt] z[nt] : C independent accumulator chains
@@ -1529,15 +1551,15 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_pipe(NetDesc nd, const fl
                 // ---- next tile: output map, z of its top hidden layer --------------------------------------------------------------
                 if (have_next) {
                     if (!PREF) {
-                        load_point(tile + nvb);
-                        if constexpr (L - 1 >= 1) load_st(tile + nvb, L - 1, stn);
+                        load_point(tile + tstep);
+                        if constexpr (L - 1 >= 1) load_st(tile + tstep, L - 1, stn);
                     }
                     f32x4 zn[C];
                     if constexpr (L - 1 >= 1) output_stage(stn, zn);
                     else { f32x4 s0[C]; layer0_st<H, C, E>(w0s, xv, w, q, s0); output_stage(s0, zn); }
                     bias_sum(zn[0], NHH - 1);
                     publish_z(zn, zw);
-                    if constexpr (NHH - 1 >= 1) load_st(tile + nvb, NHH - 1, st);
+                    if constexpr (NHH - 1 >= 1) load_st(tile + tstep, NHH - 1, st);
                 }
             }
             par ^= 1;

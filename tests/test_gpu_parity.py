@@ -616,6 +616,36 @@ def test_kernel_variants_agree(kw, N, envs):
         assert len(seen) == len(envs), f"switches selected only {sorted(seen)}"
 
 
+def test_uneven_tile_split_of_large_batches_changes_nothing_but_the_order():
+    """Large batches on two workgroups per CU (f_forward, f_backward_pipe): the first-dispatched workgroup of a CU wins every arbitration
+    and would finish early, so it is given 56 % / 62 % of the CU's tiles (GPE_PIPE_SHARE / GPE_FWD_SHARE, per 1024; 0 = even).  Which
+    workgroup takes which tile only changes the order of the gradient sums: one step from the same state must agree to fp32 round-off."""
+    import os
+    kw = dict(layers=[2, 64, 64, 64, 64, 1], gamma=50.0, dx=0.01)
+    N = 540000                                   # > 64 tiles per wave-pair of the forward kernel, ragged last tile
+    scale = _scale(kw)
+    x, flat, x_bc = _inputs(kw, N, scale=scale)
+    out = []
+    for env in ({}, {"GPE_PIPE_SHARE": "0", "GPE_FWD_SHARE": "0"}, {"GPE_PIPE_SHARE": "700", "GPE_FWD_SHARE": "300"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            eng = make_engine(go.Problem(**kw), flat, x, x_bc)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        sc = eng.step()
+        out.append((sc["loss"], sc["mu"], eng.get_grad()))
+        eng.close()
+    for loss, mu, g in out[1:]:
+        assert abs(loss - out[0][0]) <= 2e-6 * abs(out[0][0])
+        assert abs(mu - out[0][1]) <= 2e-6 * abs(out[0][1])
+        assert H.rel_err(g, out[0][2]) < 3e-6
+
+
 @pytest.mark.parametrize("layers,sym,sched", [([1, 32, 32, 32, 32, 1], 5.0, go.SCHED_PLATEAU), ([1, 64, 64, 64, 1], 0.0, go.SCHED_COSINE_LOSS),
                                               ([2, 64, 64, 64, 64, 1], 0.0, go.SCHED_CONST)])
 def test_update_kernel_forms_are_bit_identical(layers, sym, sched):

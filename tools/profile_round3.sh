@@ -24,6 +24,7 @@ python3 tools/small_n_step.py 4000 3000 >> $out/small_batch.txt
 python3 tools/small_n_step.py 16384 3000 >> $out/small_batch.txt
 python3 tools/small_n_step.py 131072 2000 >> $out/small_batch.txt
 cat $out/small_batch.txt
+for n in 2048 4000 16384; do GPE_FUSE_HEAD=0 python3 tools/small_n_step.py $n 3000 >> $out/small_batch_nohead.txt; done
 python3 bench.py --steps 20 --warmup 5 > $out/bench_ns_2d_4x64.json 2> $out/bench_ns.err
 cut -c1-300 $out/bench_ns_2d_4x64.json
 rm -rf $out/pmc
