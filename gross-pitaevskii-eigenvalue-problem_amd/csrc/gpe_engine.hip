@@ -355,6 +355,7 @@ struct gpe_engine {
     bool fuse_seed = true;         // small batches: the pipelined reverse kernel forms the seeds itself (GPE_FUSE_SEED=0: k_seed_pde)
     bool seedf_now = false;        // ... for the reverse pass being enqueued
     int64_t fuse_seed_max = 65536; // ... up to this many points (beyond, the redundant seed arithmetic of the four waves costs more than the launch)
+    int share_min_tiles = 16;      // ... for batches of at least this many tiles per workgroup (per wave in the forward kernel)
     int fwd_share = 640;           // f_forward: the same for its waves (GPE_FWD_SHARE; measured flat between 608 and 672: NS step 2.703 -> 2.688 ms)
     int pipe_share = 576;          // f_backward_pipe: share (/1024) of a CU's tiles for its first-dispatched workgroup; 0 = even (GPE_PIPE_SHARE;
                                    // NS reverse kernel 1.741 ms even, 1.727 / 1.719 / 1.715 / 1.730 / 1.741 ms at 544 / 576 / 592 / 608 / 640)
@@ -618,7 +619,7 @@ static void launch_f_forward(gpe_engine* e, Batch& b, unsigned grid, int store) 
         }
     }
     // large batches on two workgroups per CU: uneven split of each CU's tiles between its two workgroups (GPE_FWD_SHARE, / 1024)
-    const int fshare = (e->fwd_share > 0 && grid == (unsigned)(2 * e->num_cu) && (b.n + 15) / 16 >= 64 * (int64_t)grid) ? e->fwd_share : 0;
+    const int fshare = (e->fwd_share > 0 && grid == (unsigned)(2 * e->num_cu) && (b.n + 15) / 16 >= 4 * e->share_min_tiles * (int64_t)grid) ? e->fwd_share : 0;
     if constexpr (HH > 64) {
         F_LAUNCH(f_forward, HH, CC, EE, false, grid, 256, fused_fwd_lds(e, false), e->nd, e->theta, e->Wpk, b.pts, b.stored, b.O, b.n, b.ld, store, fshare);
         return;
@@ -731,7 +732,7 @@ static void launch_coop_no(gpe_engine* e, Batch& b, unsigned grid, size_t lds) {
             }
             SeedArgs none{};
             // large batches on two workgroups per CU: uneven split of each CU's tiles between its two workgroups (GPE_PIPE_SHARE, / 1024)
-            if (e->pipe_share > 0 && grid == (unsigned)(2 * e->num_cu) && (b.n + 15) / 16 >= 16 * (int64_t)grid) none.old_share_q10 = e->pipe_share;
+            if (e->pipe_share > 0 && grid == (unsigned)(2 * e->num_cu) && (b.n + 15) / 16 >= e->share_min_tiles * (int64_t)grid) none.old_share_q10 = e->pipe_share;
             switch (e->nd.n_lin - 2) {
                 case 1: hipLaunchKernelGGL((f_backward_pipe<HH, CC, EE, NO, 1>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS, none); break;
                 case 2: hipLaunchKernelGGL((f_backward_pipe<HH, CC, EE, NO, 2>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS, none); break;
@@ -1287,6 +1288,8 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
         if (envf4) e->fuse_seed_max = atoll(envf4);
         const char* envps = getenv("GPE_PIPE_SHARE");
         if (envps) e->pipe_share = atoi(envps);
+        const char* envsm = getenv("GPE_SHARE_MIN_TILES");
+        if (envsm && atoi(envsm) > 0) e->share_min_tiles = atoi(envsm);
         const char* envfs = getenv("GPE_FWD_SHARE");
         if (envfs) e->fwd_share = atoi(envfs);
         const char* envf5 = getenv("GPE_FUSE_HEAD");
