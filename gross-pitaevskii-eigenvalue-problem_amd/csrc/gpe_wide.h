@@ -343,8 +343,6 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
     const int64_t ntiles = (N + 15) >> 4;
     const int ktile = h * KTL + w;                               // this wave's feature tile of layer j-1
     for (int i = threadIdx.x; i < 7 * H + 4; i += NTHR) gb[i] = 0.f; // gb, g0 and go are contiguous
-    if constexpr (PIPE)
-        for (int i = threadIdx.x; i < (2 * ZSZ + 2 * XSZ) / 4; i += NTHR) reinterpret_cast<f32x4*>(ZB)[i] = (f32x4)(0.f);
     if constexpr (FIRST || TOP > 0) stage_layer0<H>(w0s, theta, nd, NTHR);
     const float* Wo = w0s + (4 + L - 1) * H;
     const float* wmap = WpkT + (size_t)(j - 1) * H * H;
@@ -568,8 +566,7 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
         // H = 128, C <= 4: one workgroup per CU anyway, so both exchange buffers are doubled (137 KB) and the weight-gradient products of
         // a tile are DEFERRED behind the adjoint phase of the next one -- ONE barrier per tile, and between two barriers every wave has
         // adjoint products, activation arithmetic and weight-gradient products in a row: the two waves of a SIMD fall out of step by
-        // themselves and one's VALU work runs under the other's matrix work.  (The second pair of buffers starts as zeros: the first
-        // interval's deferred products add nothing.)
+        // themselves and one's VALU work runs under the other's matrix work.  (The first interval has no deferred products.)
         float *zr = ZB, *zw = ZB + ZSZ, *xw = XT, *xr = XT + XSZ;
         const int wu = __builtin_amdgcn_readfirstlane(w);
         for (int64_t tile = g; tile < ntiles; tile += G) {
@@ -587,7 +584,7 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
                 // activation arithmetic then runs under the other's matrix work instead of both reaching it together
                 if (more) issue_loads(tile + G);
                 __builtin_amdgcn_sched_barrier(0);
-                product_phase(zw, xr);
+                if (tile != g) product_phase(zw, xr);
                 WSTAMP(7);
                 adjoint_phase(tile, zr, xw);
                 if (more) load_st(tile + G);
@@ -597,7 +594,7 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
                 if (more) { issue_loads(tile + G); load_st(tile + G); }  // in flight behind the products below
                 __builtin_amdgcn_sched_barrier(0);
                 WSTAMP(5);
-                product_phase(zw, xr);                           // previous tile: own rows of zw, all of xr
+                if (tile != g) product_phase(zw, xr);            // previous tile: own rows of zw, all of xr (the first interval has none)
                 WSTAMP(7);
             }
             if (more) publish(zw);                               // next tile's zbar_j over the rows just read
@@ -605,7 +602,7 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
             t0 = xr; xr = xw; xw = t0;
         }
         __syncthreads();
-        product_phase(zw, xr);                                   // the last tile's products (zeros if this workgroup had no tile)
+        if (g < ntiles) product_phase(zw, xr);                   // the last tile's products
     } else {
         // Two barriers per tile.  After X: ZB holds zbar_j of the tile (all rows) and XT is free.  After Y: XT holds X_{j-1} of the tile and
         // nobody reads ZB any more -- so the weight-gradient products (own rows of ZB re-read transposed, XT) are followed by the NEXT
