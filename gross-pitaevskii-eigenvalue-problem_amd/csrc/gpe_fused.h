@@ -1454,6 +1454,7 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_pipe(NetDesc nd, const fl
         g_trace[(vb * 4 + w) * 32 + 25] = st_last;       // tile loop entered
     }
 #endif
+    bool first_tile = true;
     for (; tile < tend; tile += tstep) {
         const bool have_next = tile + tstep < tend;
         float xv_t[3] = {xv[0], xv[1], xv[2]};         // this tile's coordinates (layer 0 recompute, layer-0 gradients)
@@ -1491,9 +1492,9 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_pipe(NetDesc nd, const fl
                         acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j - 1][nt][s2], bf[c][s2], acc[c], 0, 0, 0);
             }
             // deferred weight-gradient product, dW[rows of this slice][all columns] += Z^T X with NT independent accumulator chains: map
-            // j+1 of this tile, or map 1 of the previous tile (the very first interval multiplies the zeros the buffers start with).
+            // j+1 of this tile, or map 1 of the previous tile.
             // Z^T: own slice of the write-side z buffer, two intervals old, read feature-on-lane
-            {
+            if (j < NHH || !first_tile) {                      // (the very first interval of the workgroup has no product behind it)
                 f32x4 (&dw)[NT] = dwacc[j < NHH ? j : 0];
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
@@ -1564,6 +1565,7 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_pipe(NetDesc nd, const fl
             }
             par ^= 1;
         }
+        first_tile = false;
     }
 #ifdef GPE_STAMP
     if (lane == 0) for (int i = 0; i < 3; ++i) atomicAdd(&g_stamps[4 * w + i], st_acc[i]);
