@@ -134,6 +134,15 @@ GPE_DEV void update_core(int P, float* __restrict__ theta, float* __restrict__ a
     const OptDev* odr = MULTI ? &snap->od : od;                    // state the step size is derived from
     const bool lead = !MULTI || blockIdx.x == 0;                   // the workgroup that writes the optimiser state / record / history
     const int lo = MULTI ? blockIdx.x * upd_chunk(P) : 0, hi = MULTI ? min(P, lo + upd_chunk(P)) : P;
+    // the scalars thread 0 needs behind the norm are requested NOW, beside the elements: one round trip less in its serial section
+    double p_num = 0.0, p_den = 0.0, p_bcse = 0.0, p_lr = 0.0, p_b1p = 0.0, p_b2p = 0.0;
+    float p_sr2 = 0.f;
+    long long p_step = 0;
+    int p_stopped = 0;
+    if (threadIdx.x == 0) {
+        p_num = sums[S_NUM]; p_den = sums[S_DEN]; p_bcse = lsums[LS_BC_SE2]; p_sr2 = grad[P + GT_SUM_R2];
+        p_lr = odr->lr; p_b1p = odr->b1p; p_b2p = odr->b2p; p_step = odr->step; p_stopped = odr->stopped;
+    }
     if constexpr (!MULTI) {
         double acc = 0.0;
         if (cached) {
@@ -158,13 +167,13 @@ GPE_DEV void update_core(int P, float* __restrict__ theta, float* __restrict__ a
         if constexpr (MULTI) { for (int i = 0; i < UPD_G; ++i) tot += snap->part[i]; }
         else { for (int i = 0; i < 16; ++i) tot += red[i]; }
         double gn = sqrt(tot);
-        double num = sums[S_NUM], den = sums[S_DEN];
+        double num = p_num, den = p_den;
         double lam = (double)(float)(num / den);
         double I = (double)((float)den * ph.dx);
-        double sr2 = (double)grad[P + GT_SUM_R2];
+        double sr2 = (double)p_sr2;
         double pde = sr2 / ph.n_global;
         double nrm = (I - 1.0) * (I - 1.0);
-        double bc = bc_cnt > 0 ? lsums[LS_BC_SE2] / bc_cnt : 0.0;
+        double bc = bc_cnt > 0 ? p_bcse / bc_cnt : 0.0;
         double sym = ph.w_sym != 0.f ? sums[S_SYM] / ph.n_global : 0.0;
         double orth = 0.0;
         for (int j = 0; j < ph.n_orth; ++j) { double oj = sums[S_ORTH0 + j] * ph.dx; orth += oj * oj; }
@@ -180,13 +189,13 @@ GPE_DEV void update_core(int P, float* __restrict__ theta, float* __restrict__ a
             lam = 0.0; pde = 0.0; nrm = 0.0; bc = 0.0; sym = 0.0; orth = 0.0; riesz = 0.0;
         }
         int skip = !(isfinite(loss) && isfinite(gn));
-        const int frozen = do_update && odr->stopped;
-        long long step = odr->step + (do_update && !skip && !frozen ? 1 : 0);
-        double lr = odr->lr;
+        const int frozen = do_update && p_stopped;
+        long long step = p_step + (do_update && !skip && !frozen ? 1 : 0);
+        double lr = p_lr;
         float coef = 1.0f;
         if (oc.clip_norm > 0.f && !mse_mode) coef = (float)fmin(1.0, (double)oc.clip_norm / (gn + 1e-6));
         const bool commit = do_update && !skip && !frozen;
-        const double b1p = commit ? odr->b1p * (double)oc.beta1 : odr->b1p, b2p = commit ? odr->b2p * (double)oc.beta2 : odr->b2p;
+        const double b1p = commit ? p_b1p * (double)oc.beta1 : p_b1p, b2p = commit ? p_b2p * (double)oc.beta2 : p_b2p;
         if (commit && lead) { od->b1p = b1p; od->b2p = b2p; }
         double bc1 = 1.0 - b1p;
         double bc2 = 1.0 - b2p;

@@ -1271,30 +1271,6 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_pipe(NetDesc nd, const fl
     for (int s2 = 0; s2 < 4; ++s2) ztr[s2] = 4 * (((4 * q + s2) ^ (m >> 2)) + 16 * (m >> 2)) + (m & 3);
 
     float s_lam = 0.f, s_I = 0.f;
-    if constexpr (SEEDF) {
-        if (sa.slots) {                                   // the forward kernel left per-workgroup (num, den, bse): add them in index order
-            double* sd = reinterpret_cast<double*>(ZB);   // (scratch: the exchange buffers are zeroed right after)
-            for (int i = tix; i < sa.nslots * 3; i += NTHR) sd[i] = sa.slots[(size_t)(i / 3) * 4 + i % 3];
-            __syncthreads();
-            if (tix < 3) {
-                double t = 0.0;
-                for (int b = 0; b < sa.nslots; ++b) t += sd[b * 3 + tix];
-                sd[sa.nslots * 3 + tix] = t;
-            }
-            __syncthreads();
-            const double tn = sd[sa.nslots * 3], td = sd[sa.nslots * 3 + 1], tb = sd[sa.nslots * 3 + 2];
-            s_lam = (float)(tn / td);
-            s_I = (float)td * sa.ph.dx;
-            if (vb == 0 && tix == 0) {                    // ... and file the totals where k_update reads them (a separate boundary batch adds its own)
-                sa.sums_out[S_NUM] = tn; sa.sums_out[S_DEN] = td;
-                if (tb != 0.0) atomicAdd(&sa.lsums_out[LS_BC_SE2], tb);
-            }
-            __syncthreads();
-        } else {
-            s_lam = (float)(sa.sums[S_NUM] / sa.sums[S_DEN]);
-            s_I = (float)sa.sums[S_DEN] * sa.ph.dx;
-        }
-    }
     for (int i = tix; i < ((n_gsm + 3) & ~3) + 4 * H; i += NTHR) gsm[i] = 0.f;      // gsm and g0 are contiguous
     // exchange buffers start as zeros: the first interval's deferred product (no tile before it) then adds nothing -- no special case
     for (int i = tix; i < 4 * ZSZ / 4; i += NTHR) reinterpret_cast<f32x4*>(ZB)[i] = (f32x4)(0.f);
@@ -1302,7 +1278,11 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_pipe(NetDesc nd, const fl
     float xv[3] = {0.f, 0.f, 0.f};
     float ob[NOUT][C];
     double r2acc = 0.0;                                // SEEDF: sum of r^2 over this workgroup's collocation rows (wave 0, q = 0 lanes)
-    auto load_point = [&](int64_t tile) {              // coordinates and output-jet adjoints of the lane's point
+    // coordinates and output-jet adjoints of the lane's point, in two steps: the loads (fetch_point), and -- SEEDF -- the seed arithmetic on
+    // what they returned (seed_fetched), which needs lambda and the norm integral
+    float pf_u = 0.f, pf_Hu = 0.f, pf_V = 0.f;
+    int pf_kind = 0;                                   // SEEDF: 1 = collocation row (seeds formed here), 0 = seeds read / padding
+    auto fetch_point = [&](int64_t tile) {
         const int64_t pm = tile * 16 + m;
         const bool valid = pm < N;
         const int64_t pl = valid ? pm : N - 1;
@@ -1310,10 +1290,11 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_pipe(NetDesc nd, const fl
         for (int k = 0; k < 3; ++k) if (k < dim) xv[k] = pts_at(x, pl, dim, k);
         if constexpr (SEEDF) {
             if (valid && pm < sa.n_pde) {                  // collocation row: seeds from u, H u, lambda, the norm integral
-                const float V = potential_at(sa.ph, xv, sa.Vpre, pm);
-                const float r2 = seed_point<C, E>(sa.ph, xv, V, sa.u[pm], sa.Hu[pm], s_lam, s_I, ob[0]);
-                if (w == 0 && q == 0) r2acc += (double)r2;
+                pf_kind = 1;
+                pf_u = sa.u[pm]; pf_Hu = sa.Hu[pm];
+                if (sa.ph.potential == GPE_POT_PRECOMPUTED) pf_V = sa.Vpre[pm];
             } else {                                       // boundary row riding in the batch (seeded by the head kernel) / padding
+                pf_kind = 0;
 #pragma unroll
                 for (int c = 0; c < C; ++c) ob[0][c] = valid ? Ob[(int64_t)c * ld + pm] : 0.f;
             }
@@ -1324,6 +1305,16 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_pipe(NetDesc nd, const fl
             for (int c = 0; c < C; ++c) ob[o][c] = valid ? Ob[((int64_t)c * NOUT + o) * ld + pm] : 0.f;
         }
     };
+    auto seed_fetched = [&]() {
+        if constexpr (SEEDF) {
+            if (pf_kind == 1) {
+                const float V = sa.ph.potential == GPE_POT_PRECOMPUTED ? pf_V : potential_at(sa.ph, xv, nullptr, 0);
+                const float r2 = seed_point<C, E>(sa.ph, xv, V, pf_u, pf_Hu, s_lam, s_I, ob[0]);
+                if (w == 0 && q == 0) r2acc += (double)r2;
+            }
+        }
+    };
+    auto load_point = [&](int64_t tile) { fetch_point(tile); seed_fetched(); };
     // stored (t, z_k, z_L) of hidden layer h >= 1 of a tile, this wave's slice: the tile's block [L-1][C][NT][256] behind one descriptor
     auto load_st = [&](int64_t tile, int h, f32x4 (&st)[C]) {
         const buf_t rS = buf_make(stored + (size_t)tile * (L - 1) * C * NT * 256, (unsigned)((L - 1) * C * NT * 1024));
@@ -1369,9 +1360,43 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_pipe(NetDesc nd, const fl
     }
     f32x4 stl0[C];
     if (tile < tend) {
-        load_point(tile);
+        fetch_point(tile);
         if constexpr (L - 1 >= 1) load_st(tile, L - 1, stl0);
     }
+    // lambda and the norm integral: from the step sums, or -- the forward kernel ran the head -- from its per-workgroup triples, which are
+    // requested HERE, behind the weight fragments and the first tile's data: one round trip for all of them
+    if constexpr (SEEDF) {
+        if (sa.slots) {                                   // the forward kernel left per-workgroup (num, den, bse): add them in a FIXED tree
+            double* sd = reinterpret_cast<double*>(XT);   // (scratch: three doubles of an exchange buffer, put back to zero below)
+            if (tix < 64) {                               // lane l: slots l, l + 64, ... in order; then a butterfly over the 64 lanes
+                double t3[3] = {0.0, 0.0, 0.0};
+                for (int b = tix; b < sa.nslots; b += 64) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) t3[i] += sa.slots[(size_t)b * 4 + i];
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) t3[i] += __shfl_xor(t3[i], o, 64);
+                }
+                if (tix == 0) { sd[0] = t3[0]; sd[1] = t3[1]; sd[2] = t3[2]; }
+            }
+            __syncthreads();
+            const double tn = sd[0], td = sd[1], tb = sd[2];
+            s_lam = (float)(tn / td);
+            s_I = (float)td * sa.ph.dx;
+            if (vb == 0 && tix == 0) {                    // ... and file the totals where k_update reads them (a separate boundary batch adds its own)
+                sa.sums_out[S_NUM] = tn; sa.sums_out[S_DEN] = td;
+                if (tb != 0.0) atomicAdd(&sa.lsums_out[LS_BC_SE2], tb);
+            }
+            __syncthreads();
+            if (tix == 0) { sd[0] = 0.0; sd[1] = 0.0; sd[2] = 0.0; }      // (ordered before the tile loop by the barrier below)
+        } else {
+            s_lam = (float)(sa.sums[S_NUM] / sa.sums[S_DEN]);
+            s_I = (float)sa.sums[S_DEN] * sa.ph.dx;
+        }
+    }
+    if (tile < tend) seed_fetched();
     // the weight fragments have landed before the tile loop is entered, and the compiler knows it: else its wait-count bookkeeping
     // (loop-entry state merged with the back edge) puts vmcnt waits in front of the first product phase of every tile, where
     // they stall the matrix instructions on the stored-activation loads that were only just requested
