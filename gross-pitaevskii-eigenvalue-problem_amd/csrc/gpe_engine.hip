@@ -372,6 +372,8 @@ struct gpe_engine {
     int64_t fuse_head_max = 6144;  // up to this many points (measured: 43.2 vs 46.5 us at 4 000, equal at 6 000, 64.3 vs 62.9 us at 8 192)
     bool fh_want = false;          // gpe_step / graph capture in progress: nobody reads the step sums between the passes
     bool fh_now = false;           // the forward pass of this step left per-workgroup head sums in head_slots
+    int fh_nslots = 0;             // ... this many triples (= workgroups of that forward launch)
+    int64_t fuse_head_tile_min = 32769;   // f_forward (per-wave tiles) runs the head from this many points on (GPE_FUSE_HEAD_TILE_MIN)
     double* head_slots = nullptr;  // [HEAD_SLOTS][4]
     UpdSnap* upd_snap = nullptr;   // multi-workgroup update (P >= UPD_MULTI_MIN): partial norms + snapshot of sums / optimiser state
     gpe_scalars *hist = nullptr, *last = nullptr;
@@ -571,13 +573,21 @@ static bool fwd_coop(gpe_engine* e, const Batch& b) {
 static bool seed_in_reverse(gpe_engine* e);
 // whole steps (gpe_step / gpe_run) of the small-batch class whose reverse kernel forms the seeds: the cooperative forward kernel runs
 // the head too, k_head_pde is not launched and the step sums are added in a fixed order
-static bool head_fusable(gpe_engine* e) {
-    return e->fuse_head && e->head_slots && e->H <= 64 && e->main.n <= e->fuse_head_max && fwd_coop(e, e->main) && seed_in_reverse(e) &&
-           fused_grid(e, e->main.n, 1, 2) <= HEAD_SLOTS;
+// problem class whose head the forward kernels can run (head_point_real): real psi, no orthogonality / Riesz / symmetry terms
+static bool head_class(gpe_engine* e) {
+    return e->fuse_head && e->head_slots && e->path == GPE_PATH_FUSED && !e->wide && e->H <= 64 && e->nd.n_out == 1 && !e->cfg.complex_psi &&
+           e->ph.n_orth == 0 && e->cfg.w_riesz == 0.f && e->cfg.w_sym == 0.f && e->main.C >= 3 && e->main.n > 0;
 }
-static bool head_in_forward(gpe_engine* e) {
-    return e->fuse_head && e->fh_want && head_fusable(e);
+// ... by the cooperative forward kernel (small batches; the reverse kernel forms the seeds and adds the triples)
+static bool head_fusable_coop(gpe_engine* e) {
+    return head_class(e) && e->main.n <= e->fuse_head_max && fwd_coop(e, e->main) && seed_in_reverse(e) && fused_grid(e, e->main.n, 1, 2) <= HEAD_SLOTS;
 }
+// ... by the per-wave-tile forward kernel (large batches; k_seed_pde, or the seed-forming reverse kernel, adds the triples)
+static bool head_fusable_tile(gpe_engine* e) {
+    return head_class(e) && !fwd_coop(e, e->main) && !e->fwd_b6 && e->main.n >= e->fuse_head_tile_min && fused_grid(e, e->main.n, 4, 2) <= HEAD_SLOTS;
+}
+static bool head_fusable(gpe_engine* e) { return head_fusable_coop(e) || head_fusable_tile(e); }
+static bool head_in_forward(gpe_engine* e) { return e->fuse_head && e->fh_want && head_fusable(e); }
 template <int HH, int CC, int EE, int NO>
 static void launch_fcoop_no(gpe_engine* e, Batch& b, unsigned grid, size_t lds, int store) {
 #define CARGS e->nd, e->theta, e->Wpk, b.pts, b.stored, b.O, b.n, b.ld, store
@@ -629,8 +639,9 @@ static void launch_f_forward(gpe_engine* e, Batch& b, unsigned grid, int store) 
     }
     // large batches on two workgroups per CU: uneven split of each CU's tiles between its two workgroups (GPE_FWD_SHARE, / 1024)
     const int fshare = (e->fwd_share > 0 && grid == (unsigned)(2 * e->num_cu) && (b.n + 15) / 16 >= 4 * e->share_min_tiles * (int64_t)grid) ? e->fwd_share : 0;
+    const HeadArgs nohead{};
     if constexpr (HH > 64) {
-        F_LAUNCH(f_forward, HH, CC, EE, false, grid, 256, fused_fwd_lds(e, false), e->nd, e->theta, e->Wpk, b.pts, b.stored, b.O, b.n, b.ld, store, fshare);
+        F_LAUNCH(f_forward, HH, CC, EE, false, grid, 256, fused_fwd_lds(e, false), e->nd, e->theta, e->Wpk, b.pts, b.stored, b.O, b.n, b.ld, store, fshare, nohead);
         return;
     }
     if constexpr (HH <= 64) {
@@ -656,10 +667,22 @@ static void launch_f_forward(gpe_engine* e, Batch& b, unsigned grid, int store) 
             return;
         }
     }
+    if constexpr (HH <= 64 && CC >= 3) {
+        if (e->fh_now && &b == &e->main && e->nd.n_out == 1) {     // whole step, large batch: the head rides in this kernel
+            const HeadArgs ha{e->ph, e->base_norm, b.V, (const float* const*)e->orth_dev, e->bc_target, b.u, b.Hu, b.Ob, e->n_pde, b.ld, e->head_slots};
+            if (e->fwd_wlds && staged_batch(e, b))
+                hipLaunchKernelGGL((f_forward<HH, CC, EE, 1, true, true>), dim3(grid), dim3(256), fused_fwd_lds(e, true), e->stream, e->nd, e->theta, e->Wpk,
+                                   b.pts, b.stored, b.O, b.n, b.ld, store, fshare, ha);
+            else
+                hipLaunchKernelGGL((f_forward<HH, CC, EE, 1, false, true>), dim3(grid), dim3(256), fused_fwd_lds(e, false), e->stream, e->nd, e->theta, e->Wpk,
+                                   b.pts, b.stored, b.O, b.n, b.ld, store, fshare, ha);
+            return;
+        }
+    }
     if (e->fwd_wlds && staged_batch(e, b))
-        F_LAUNCH(f_forward, HH, CC, EE, true, grid, 256, fused_fwd_lds(e, true), e->nd, e->theta, e->Wpk, b.pts, b.stored, b.O, b.n, b.ld, store, fshare);
+        F_LAUNCH(f_forward, HH, CC, EE, true, grid, 256, fused_fwd_lds(e, true), e->nd, e->theta, e->Wpk, b.pts, b.stored, b.O, b.n, b.ld, store, fshare, nohead);
     else
-        F_LAUNCH(f_forward, HH, CC, EE, false, grid, 256, fused_fwd_lds(e, false), e->nd, e->theta, e->Wpk, b.pts, b.stored, b.O, b.n, b.ld, store, fshare);
+        F_LAUNCH(f_forward, HH, CC, EE, false, grid, 256, fused_fwd_lds(e, false), e->nd, e->theta, e->Wpk, b.pts, b.stored, b.O, b.n, b.ld, store, fshare, nohead);
 }
 // reverse-kernel variant for one batch: 3 = cooperative (a workgroup per tile, a wave per 16-feature slice),
 // 2 = weight gradients in registers (1 wave/SIMD),
@@ -729,7 +752,7 @@ static void launch_coop_no(gpe_engine* e, Batch& b, unsigned grid, size_t lds) {
             if constexpr (NO == 1 && CC >= 3) {
                 if (e->seedf_now && &b == &e->main) {       // small batch: the kernel forms the seeds itself (k_seed_pde was not launched)
                     const SeedArgs sa{e->ph, b.V, b.u, b.Hu, (const double*)e->sums(), e->dsc(), e->n_pde,
-                                      e->fh_now ? (const double*)e->head_slots : nullptr, e->fh_now ? (int)fused_grid(e, b.n, 1, 2) : 0,
+                                      e->fh_now ? (const double*)e->head_slots : nullptr, e->fh_now ? e->fh_nslots : 0,
                                       e->sums(), e->lsums(), 0};
                     switch (e->nd.n_lin - 2) {
                         case 1: hipLaunchKernelGGL((f_backward_pipe<HH, CC, EE, 1, 1, true>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS, sa); break;
@@ -1176,7 +1199,7 @@ int gpe_active_kernels(gpe_engine* e, char* buf, size_t n) {
         else if (kind == 2) snprintf(r, sizeof r, "f_backward<%d,%d,%d,%d,wlds,racc%d>", e->H, b.C, b.E, e->nd.n_out, maps > 3 ? 3 : maps);
         else snprintf(r, sizeof r, "f_backward<%d,%d,%d,%d,l2,%s>", e->H, b.C, b.E, e->nd.n_out, e->H > 64 ? "gacc" : "ldsacc");
         // (whole steps, gpe_step / gpe_run: the split-phase protocol of the data-parallel driver keeps k_head_pde)
-        if (fc && head_fusable(e))
+        if (fc ? head_fusable_coop(e) : head_fusable_tile(e))
             snprintf(f + strlen(f) - 1, sizeof f - strlen(f) + 1, ",head>");
     } else {
         const int W = e->nd.width[1];
@@ -1303,6 +1326,8 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
         if (envfs) e->fwd_share = atoi(envfs);
         const char* envf5 = getenv("GPE_FUSE_HEAD");
         e->fuse_head = !(envf5 && atoi(envf5) == 0);
+        const char* envf7 = getenv("GPE_FUSE_HEAD_TILE_MIN");
+        if (envf7) e->fuse_head_tile_min = atoll(envf7);
         const char* envf6 = getenv("GPE_FUSE_HEAD_MAX");
         if (envf6) e->fuse_head_max = atoll(envf6);
         if (ok && e->fuse_head) ok = alloc((void**)&e->head_slots, (size_t)HEAD_SLOTS * 4 * sizeof(double));
@@ -1645,7 +1670,8 @@ static int launch_seed_pde(gpe_engine* e, float* d_resid, int want_seeds) {
     dim3 g(head_grid(e, e->n_pde));
     DISPATCH_TRAIN(b, hipLaunchKernelGGL((k_seed_pde<CC, EE>), g, dim3(256), 0, e->stream, e->ph, b.pts, b.V,
                                         (const float* const*)e->orth_dev, b.u, b.Hu, b.ux, e->sums(), b.Ob, d_resid, e->dsc(),
-                                        e->n_pde, b.ld, want_seeds));      // collocation rows only; boundary rows were seeded by the head kernel
+                                        e->n_pde, b.ld, want_seeds, e->fh_now ? (const double*)e->head_slots : (const double*)nullptr,
+                                        e->fh_now ? e->fh_nslots : 0, e->sums(), e->lsums()));      // collocation rows only; boundary rows were seeded by the head kernel
     HIPCHK(e, hipGetLastError());
     return GPE_OK;
 }
@@ -1661,6 +1687,7 @@ int gpe_step_begin(gpe_engine* e) {
     if ((rc = launch_begin(e))) return rc;
     if ((rc = bc_fork(e, true))) return rc;
     e->fh_now = head_in_forward(e);
+    if (e->fh_now) e->fh_nslots = (int)(head_fusable_coop(e) ? fused_grid(e, e->main.n, 1, 2) : fused_grid(e, e->main.n, 4, 2));
     if ((rc = mlp_forward(e, e->main, true))) { e->fh_now = false; return rc; }
     if (!e->fh_now && (rc = launch_head_pde(e))) return rc;
     if (e->cfg.w_sym != 0.f) {

@@ -112,12 +112,18 @@ __global__ void k_begin(NetDesc nd, int H, const float* __restrict__ theta, floa
 
 // WLDS: the packed hidden-hidden weights ((L-1)*H*H floats) are staged once per workgroup into LDS and the MFMA A
 // operands are read from there (ds_read_b128, ~100 cycles) instead of from L2 (~600 cycles) right before each use.
-template <int H, int C, int E, int NOUT, bool WLDS>
+// HEADF (whole steps of real psi without orthogonality / Riesz / symmetry terms, batches beyond the cooperative kernel's range): the wave
+// also runs the head of its tile's rows (head_point_real on the q = 0 lanes, which hold the point's output jets after the reduction) and
+// the workgroup leaves one (num, den, bse) triple in ha.slots -- k_head_pde is not launched (36.8 us of the NS step), the consumer
+// (k_seed_pde, or the reverse kernel that forms the seeds itself) adds the triples in a fixed order.
+template <int H, int C, int E, int NOUT, bool WLDS, bool HEADF = false>
 __global__ __launch_bounds__(256, ((C <= 5 && H <= 64) ? GPE_FWD_WAVES : 1)) void f_forward(NetDesc nd, const float* __restrict__ theta,
                                                                  const float* __restrict__ Wpk,
                                                                  Pts x, float* __restrict__ stored,
                                                                  float* __restrict__ O, int64_t N, int64_t ld,
-                                                                 int store_acts, int old_share_q10) {
+                                                                 int store_acts, int old_share_q10, HeadArgs ha) {
+    static_assert(!HEADF || NOUT == 1, "head in the forward kernel: real psi");
+    double hnum = 0.0, hden = 0.0, hbse = 0.0;                   // HEADF: this lane's partial sums (q = 0 lanes)
     constexpr int D = C - 1 - E, NT = H / 16, NF = NT * 4;
     const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4;
     const unsigned lane4 = (unsigned)lane * 4u;
@@ -248,6 +254,10 @@ __global__ __launch_bounds__(256, ((C <= 5 && H <= 64) ? GPE_FWD_WAVES : 1)) voi
                     v += __shfl_xor(v, 32, 64);
                     if (c == 0) v += bo[o];
                     if (q == 0 && valid) O[((int64_t)c * NOUT + o) * ld + pm] = v;
+                    if constexpr (HEADF) part[c] = v;
+                }
+                if constexpr (HEADF) {
+                    if (q == 0 && valid) head_point_real<C, E>(ha, xv, pm, N, part, hnum, hden, hbse);
                 }
             }
         };
@@ -255,6 +265,24 @@ __global__ __launch_bounds__(256, ((C <= 5 && H <= 64) ? GPE_FWD_WAVES : 1)) voi
         for (; j + 1 < L; j += 2) { layer(bufA, bufB, j); layer(bufB, bufA, j + 1); }   // ping-pong: no register copies
         if (j < L) { layer(bufA, bufB, j); output(bufB); }
         else output(bufA);
+    }
+    if constexpr (HEADF) {                                       // lanes -> wave -> workgroup, each in a fixed order
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            hnum += __shfl_xor(hnum, o, 64);
+            hden += __shfl_xor(hden, o, 64);
+            hbse += __shfl_xor(hbse, o, 64);
+        }
+        __syncthreads();                                         // every wave is done with the LDS copies of the small parameters
+        double* hred = reinterpret_cast<double*>(lds_f);
+        const int wv = threadIdx.x >> 6;
+        if (lane == 0) { hred[wv * 3 + 0] = hnum; hred[wv * 3 + 1] = hden; hred[wv * 3 + 2] = hbse; }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            double t = 0.0;
+            for (int k = 0; k < 4; ++k) t += hred[k * 3 + threadIdx.x];
+            ha.slots[(size_t)blockIdx.x * 4 + threadIdx.x] = t;
+        }
     }
 }
 

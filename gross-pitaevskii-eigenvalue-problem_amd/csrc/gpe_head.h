@@ -218,13 +218,37 @@ __global__ __launch_bounds__(256) void k_seed_pde(Phys ph, Pts x, const float* _
                                                   const float* __restrict__ ux_in,
                                                   const double* __restrict__ sums, float* __restrict__ Ob,
                                                   float* __restrict__ resid_out, double* __restrict__ sum_r2, int64_t N,
-                                                  int64_t ld, int want_seeds) {
+                                                  int64_t ld, int want_seeds, const double* __restrict__ slots, int nslots,
+                                                  double* __restrict__ sums_out, double* __restrict__ lsums_out) {
     constexpr int D = C - 1 - E;
     __shared__ double red[4];
     double sr2 = 0.0;
+    double num, den;
+    if (slots) {      // the forward kernel ran the head (HeadArgs) and left one (num, den, bse) triple per workgroup: add them in a fixed tree
+        __shared__ double tot[3];
+        if (threadIdx.x < 64) {
+            double t3[3] = {0.0, 0.0, 0.0};
+            for (int b = threadIdx.x; b < nslots; b += 64) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) t3[i] += slots[(size_t)b * 4 + i];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) t3[i] += __shfl_xor(t3[i], o, 64);
+            }
+            if (threadIdx.x == 0) { tot[0] = t3[0]; tot[1] = t3[1]; tot[2] = t3[2]; }
+        }
+        __syncthreads();
+        num = tot[0]; den = tot[1];
+        if (blockIdx.x == 0 && threadIdx.x == 0) {        // ... and file the totals where k_update reads them
+            sums_out[S_NUM] = num; sums_out[S_DEN] = den;
+            if (tot[2] != 0.0) atomicAdd(&lsums_out[LS_BC_SE2], tot[2]);
+        }
+    } else { num = sums[S_NUM]; den = sums[S_DEN]; }
     for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < N; m += (int64_t)gridDim.x * 256) {
-        float lam = (float)(sums[S_NUM] / sums[S_DEN]);
-        float I = (float)sums[S_DEN] * ph.dx;
+        float lam = (float)(num / den);
+        float I = (float)den * ph.dx;
         float xv[3] = {0.f, 0.f, 0.f};
         for (int k = 0; k < ph.dim; ++k) xv[k] = pts_at(x, m, ph.dim, k);
         float V = potential_at(ph, xv, Vpre, m);

@@ -625,8 +625,9 @@ def test_uneven_tile_split_of_large_batches_changes_nothing_but_the_order():
     N = 540000                                   # > 64 tiles per wave-pair of the forward kernel, ragged last tile
     scale = _scale(kw)
     x, flat, x_bc = _inputs(kw, N, scale=scale)
-    out = []
-    for env in ({}, {"GPE_PIPE_SHARE": "0", "GPE_FWD_SHARE": "0"}, {"GPE_PIPE_SHARE": "700", "GPE_FWD_SHARE": "300"}):
+    out, names = [], []
+    # (the last row also moves the head back into its own kernel: by default f_forward runs it from 32 769 points on)
+    for env in ({}, {"GPE_PIPE_SHARE": "0", "GPE_FWD_SHARE": "0"}, {"GPE_PIPE_SHARE": "700", "GPE_FWD_SHARE": "300", "GPE_FUSE_HEAD": "0"}):
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:
@@ -637,9 +638,12 @@ def test_uneven_tile_split_of_large_batches_changes_nothing_but_the_order():
                     os.environ.pop(k, None)
                 else:
                     os.environ[k] = v
+        names.append(eng.active_kernels["fwd"])
         sc = eng.step()
         out.append((sc["loss"], sc["mu"], eng.get_grad()))
         eng.close()
+    if "GPE_FUSE_HEAD" not in os.environ and "GPE_FWD_B6" not in os.environ:
+        assert names[0].endswith(",head>") and not names[2].endswith(",head>"), names
     for loss, mu, g in out[1:]:
         assert abs(loss - out[0][0]) <= 2e-6 * abs(out[0][0])
         assert abs(mu - out[0][1]) <= 2e-6 * abs(out[0][1])
