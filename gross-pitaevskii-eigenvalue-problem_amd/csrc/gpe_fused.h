@@ -1397,11 +1397,18 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_pipe(NetDesc nd, const fl
         if (sa.slots) {                                   // the forward kernel left per-workgroup (num, den, bse): add them in a FIXED tree
             double* sd = reinterpret_cast<double*>(XT);   // (scratch: three doubles of an exchange buffer, put back to zero below)
             if (tix < 64) {                               // lane l: slots l, l + 64, ... in order; then a butterfly over the 64 lanes
-                double t3[3] = {0.0, 0.0, 0.0};
-                for (int b = tix; b < sa.nslots; b += 64) {
+                double sv[8][3];                            // (<= 512 slots: all 24 loads in flight at once, then added in order)
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) t3[i] += sa.slots[(size_t)b * 4 + i];
+                for (int k = 0; k < 8; ++k) {
+                    const int b = tix + 64 * k;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) sv[k][i] = b < sa.nslots ? sa.slots[(size_t)b * 4 + i] : 0.0;
                 }
+                double t3[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) t3[i] += sv[k][i];
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) {
 #pragma unroll

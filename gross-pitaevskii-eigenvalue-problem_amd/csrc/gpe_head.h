@@ -227,11 +227,18 @@ __global__ __launch_bounds__(256) void k_seed_pde(Phys ph, Pts x, const float* _
     if (slots) {      // the forward kernel ran the head (HeadArgs) and left one (num, den, bse) triple per workgroup: add them in a fixed tree
         __shared__ double tot[3];
         if (threadIdx.x < 64) {
-            double t3[3] = {0.0, 0.0, 0.0};
-            for (int b = threadIdx.x; b < nslots; b += 64) {
+            double sv[8][3];                                // (<= 512 slots: all 24 loads in flight at once, then added in order)
 #pragma unroll
-                for (int i = 0; i < 3; ++i) t3[i] += slots[(size_t)b * 4 + i];
+            for (int k = 0; k < 8; ++k) {
+                const int b = threadIdx.x + 64 * k;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) sv[k][i] = b < nslots ? slots[(size_t)b * 4 + i] : 0.0;
             }
+            double t3[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) t3[i] += sv[k][i];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
 #pragma unroll
