@@ -616,6 +616,37 @@ def test_kernel_variants_agree(kw, N, envs):
         assert len(seen) == len(envs), f"switches selected only {sorted(seen)}"
 
 
+@pytest.mark.parametrize("N", [4000, 50000])
+def test_head_inside_the_forward_kernel_sums_in_a_fixed_order(N):
+    """Whole steps of real-psi problems run the head inside the forward kernel (<= 6 144 points: f_forward_coop, >= 32 769: f_forward): one
+    (sum u Hu, sum u^2, sum e_bc^2) triple per workgroup, added in a fixed order by the consumer -- so lambda and the norm integral of a
+    step are reproducible bit for bit (the k_head_pde path adds with double atomics in arrival order), and agree with that path."""
+    import os
+    kw = dict(layers=[1, 64, 64, 64, 1], gamma=10.0, base_mode=0, dx=12.0 / (N - 1))
+    x, flat, x_bc = _inputs(kw, N)
+    runs = []
+    for env in ({}, {}, {"GPE_FUSE_HEAD": "0"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            eng = make_engine(go.Problem(**kw), flat, x, x_bc)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        fwd = eng.active_kernels["fwd"]
+        sc = [eng.step() for _ in range(3)]
+        runs.append((fwd, [(r["mu"], r["num"], r["den"], r["integral"]) for r in sc]))
+        eng.close()
+    if not any(k in os.environ for k in ("GPE_FUSE_HEAD", "GPE_FWD_B6", "GPE_COOP", "GPE_COOP_FWD_MAX_TILES")):
+        assert runs[0][0].endswith(",head>") and not runs[2][0].endswith(",head>"), [r[0] for r in runs]
+        assert runs[0][1][0] == runs[1][1][0]                     # first step: identical bit for bit
+    for a, b in zip(runs[0][1], runs[2][1]):
+        assert abs(a[0] - b[0]) <= 2e-6 * abs(b[0]) and abs(a[2] - b[2]) <= 2e-6 * abs(b[2])
+
+
 def test_uneven_tile_split_of_large_batches_changes_nothing_but_the_order():
     """Large batches on two workgroups per CU (f_forward, f_backward_pipe): the first-dispatched workgroup of a CU wins every arbitration
     and would finish early, so it is given 56 % / 62 % of the CU's tiles (GPE_PIPE_SHARE / GPE_FWD_SHARE, per 1024; 0 = even).  Which
