@@ -303,6 +303,9 @@ __global__ __launch_bounds__(512, 2) void w_bwd_out(NetDesc nd, const float* __r
 #undef W_TRACE_K
 #define W_TRACE_K 1
 #define W_MAP_PIPE(H, C) ((H) == 128 && (C) <= 4)
+#ifndef GPE_WIDE_ALT_PRIO
+#define GPE_WIDE_ALT_PRIO 0   // w_bwd_map: the SIMD partners alternate s_setprio per K tile inside the product phases (as w_forward does)
+#endif
 #ifndef GPE_WIDE_STAGGER
 #define GPE_WIDE_STAGGER 0    // w_bwd_map, one-barrier form: 1 = waves 4..7 run the deferred products BEFORE the adjoint phase (measured: 0.705 vs 0.735)
 #endif
@@ -480,6 +483,9 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
             }
 #pragma unroll
             for (int i = 0; i < W_KCB; ++i) {
+                if constexpr (GPE_WIDE_ALT_PRIO) {               // SIMD partners (w, w + 4) take turns at the matrix pipe, one K tile each
+                    if ((((n0 + i) & 1) == 0) == (w < W_NW / 2)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+                }
                 f32x4 bf[C];
 #pragma unroll
                 for (int c = 0; c < C; ++c) bf[c] = *reinterpret_cast<const f32x4*>(&zbuf[(c * NT + n0 + i) * 256 + zfrag]);
@@ -490,6 +496,7 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
                         acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i][s2], bf[c][s2], acc[c], 0, 0, 0);
             }
         }
+        if constexpr (GPE_WIDE_ALT_PRIO) __builtin_amdgcn_s_setprio(0);
         WSTAMP(4);
         if constexpr (GPE_WIDE_PRIO_ACT != 0) __builtin_amdgcn_s_setprio(GPE_WIDE_PRIO_ACT > 0 ? GPE_WIDE_PRIO_ACT : 0);
         // recompute X of layer j-1 (own tile), activation adjoint -> zbar_{j-1}
@@ -544,6 +551,9 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
         for (int k0 = 0; k0 < KTL; k0 += 4)
 #pragma unroll
             for (int c = 0; c < C; ++c) {
+                if constexpr (GPE_WIDE_ALT_PRIO) {
+                    if ((((k0 / 4 * C + c) & 1) == 0) == (w < W_NW / 2)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+                }
                 f32x4 xf[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -556,6 +566,7 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
                         for (int rt = 0; rt < RTZ; ++rt)
                             dwacc[rt][k0 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(zt[rt][c][s2], xf[i][s2], dwacc[rt][k0 + i], 0, 0, 0);
             }
+        if constexpr (GPE_WIDE_ALT_PRIO) __builtin_amdgcn_s_setprio(0);
     };
     if (g < ntiles) {
         issue_loads(g);
