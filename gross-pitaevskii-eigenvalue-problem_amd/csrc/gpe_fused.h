@@ -36,6 +36,9 @@
 #define GPE_BWD_WAVES 2
 #endif
 #ifndef GPE_COOP_PRIO
+#ifndef GPE_FCOOP_ALT_PRIO
+#define GPE_FCOOP_ALT_PRIO 0   // f_forward_coop<128>: SIMD partners alternate s_setprio per K tile (as w_forward does)
+#endif
 #define GPE_COOP_PRIO 1      // s_setprio level of the product phases of f_backward_coop (H <= 64); 0 switches it off
 #endif
 #ifndef GPE_PIPE_G0REG
@@ -837,6 +840,9 @@ __global__ __launch_bounds__(H * 4, 2) void f_forward_coop(NetDesc nd, const flo
             for (int c = 1; c < C; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt) {
+                if constexpr (H == 128 && GPE_FCOOP_ALT_PRIO) {   // SIMD partners (w, w + 4) take turns at the matrix pipe, one K tile each
+                    if (((kt & 1) == 0) == (w < 4)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+                }
                 f32x4 bf[C];
 #pragma unroll
                 for (int c = 0; c < C; ++c) bf[c] = *reinterpret_cast<const f32x4*>(&buf[(c * NT + kt) * 256 + lane * 4]);
@@ -847,6 +853,7 @@ __global__ __launch_bounds__(H * 4, 2) void f_forward_coop(NetDesc nd, const flo
                         acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j - 1][kt][s2], bf[c][s2], acc[c], 0, 0, 0);
             }
 
+            if constexpr (H == 128 && GPE_FCOOP_ALT_PRIO) __builtin_amdgcn_s_setprio(0);
             const f32x4 tt = gpe_tanh(acc[0]);
             act_from_stored<D, E>(tt, acc + 1, acc + 1 + D, shift, a);
             if (store_acts) {
