@@ -289,7 +289,7 @@ struct SeedArgs {
 };
 
 // block-wide sum of a double over 256 threads -> valid in thread 0
-GPE_DEV double block_sum_256(double v, double* red /* >= 4 doubles of LDS */) {
+GPE_DEV double block_sum_256(double v, double* red /* >= one double of LDS per wave of the block */) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     int w = threadIdx.x >> 6;

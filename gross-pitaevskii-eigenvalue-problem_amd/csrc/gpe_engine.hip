@@ -422,7 +422,8 @@ struct gpe_engine {
     bool merge_bc = true;
     const float* mse_target = nullptr;
     int num_cu = 256;
-    int head_wg_per_cu = 2;        // head / seed kernels: workgroups per CU (each ends in one double atomic per global sum)
+    int head_wg_per_cu = 1;        // head / seed kernels: workgroups per CU (each ends in one double atomic per global sum: ~22 ns apiece at one address)
+    int head_threads = 1024;       // ... and threads per workgroup (GPE_HEAD_THREADS; 256 x 2 per CU until round 3: half the loads in flight, twice the atomics)
     // ---- data-parallel exchange inside the engine: RCCL on a dedicated stream (gpe_comm_init) ----
     struct Rccl {
         void* dl = nullptr;
@@ -1428,6 +1429,8 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
 #endif
         const char* envh = getenv("GPE_HEAD_WG_PER_CU");
         if (envh && atoi(envh) > 0) e->head_wg_per_cu = atoi(envh);
+        const char* envht = getenv("GPE_HEAD_THREADS");
+        if (envht && (atoi(envht) == 256 || atoi(envht) == 512 || atoi(envht) == 1024)) e->head_threads = atoi(envht);
         const char* envb = getenv("GPE_MERGE_BC");
         e->merge_bc = !envb || atoi(envb) != 0;
         const char* envg = getenv("GPE_GRAPH");
@@ -1654,12 +1657,14 @@ int gpe_eval_density(gpe_engine* e, const float* d_x, int64_t n, float dx, int a
 }
 
 // ---- the step ------------------------------------------------------------------------------------------
-static unsigned head_grid(gpe_engine* e, int64_t n) { return (unsigned)std::min<int64_t>(cdiv(n, 256), (int64_t)e->num_cu * e->head_wg_per_cu); }
+static unsigned head_grid(gpe_engine* e, int64_t n, int threads = 0) {
+    return (unsigned)std::min<int64_t>(cdiv(n, threads > 0 ? threads : e->head_threads), (int64_t)e->num_cu * e->head_wg_per_cu);
+}
 
 static int launch_head_pde(gpe_engine* e) {
     Batch& b = e->main;
     dim3 g(head_grid(e, b.n));
-    DISPATCH_TRAIN(b, hipLaunchKernelGGL((k_head_pde<CC, EE>), g, dim3(256), 0, e->stream, e->ph, e->base_norm, b.pts, b.V, b.O,
+    DISPATCH_TRAIN(b, hipLaunchKernelGGL((k_head_pde<CC, EE>), g, dim3(e->head_threads), 0, e->stream, e->ph, e->base_norm, b.pts, b.V, b.O,
                                         (const float* const*)e->orth_dev, b.u, b.Hu, b.ux, e->sums(), b.n, b.ld, e->n_pde,
                                         e->bc_target, b.Ob, e->lsums()));
     HIPCHK(e, hipGetLastError());
@@ -1668,7 +1673,7 @@ static int launch_head_pde(gpe_engine* e) {
 static int launch_seed_pde(gpe_engine* e, float* d_resid, int want_seeds) {
     Batch& b = e->main;
     dim3 g(head_grid(e, e->n_pde));
-    DISPATCH_TRAIN(b, hipLaunchKernelGGL((k_seed_pde<CC, EE>), g, dim3(256), 0, e->stream, e->ph, b.pts, b.V,
+    DISPATCH_TRAIN(b, hipLaunchKernelGGL((k_seed_pde<CC, EE>), g, dim3(e->head_threads), 0, e->stream, e->ph, b.pts, b.V,
                                         (const float* const*)e->orth_dev, b.u, b.Hu, b.ux, e->sums(), b.Ob, d_resid, e->dsc(),
                                         e->n_pde, b.ld, want_seeds, e->fh_now ? (const double*)e->head_slots : (const double*)nullptr,
                                         e->fh_now ? e->fh_nslots : 0, e->sums(), e->lsums()));      // collocation rows only; boundary rows were seeded by the head kernel
@@ -1817,7 +1822,7 @@ int gpe_mse_begin(gpe_engine* e) {
     e->mse.pts = Pts{e->ux, nullptr, e->n_pde};
     if ((rc = launch_begin(e))) return rc;
     if ((rc = mlp_forward(e, e->mse, true))) return rc;
-    hipLaunchKernelGGL(k_seed_mse, dim3(head_grid(e, e->mse.n)), dim3(256), 0, e->stream, e->ph, e->mse.pts.a, e->mse_target,
+    hipLaunchKernelGGL(k_seed_mse, dim3(head_grid(e, e->mse.n, 256)), dim3(256), 0, e->stream, e->ph, e->mse.pts.a, e->mse_target,
                        e->mse.O, e->mse.Ob, e->dsc() + 2, e->mse.n, e->mse.ld);
     HIPCHK(e, hipGetLastError());
     if ((rc = mlp_backward(e, e->mse, /*close=*/true))) return rc;

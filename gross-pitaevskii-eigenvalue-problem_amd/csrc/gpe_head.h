@@ -94,7 +94,7 @@ template <int C, int E>
 // Rows [n_pde, N) of a merged batch are boundary points (refine/harmonic_pinn_simulation.py:198-210): for those the kernel
 // forms e = base + s*NN - target, adds e^2 to lsums[LS_BC_SE2] and writes their seeds Ob = w_bc*2/cnt * e * s / world directly
 // (they do not depend on mu) -- what k_head_seed_bc does for a separate boundary batch.
-__global__ __launch_bounds__(256) void k_head_pde(Phys ph, float base_norm, Pts x,
+__global__ __launch_bounds__(1024) void k_head_pde(Phys ph, float base_norm, Pts x,
                                                   const float* __restrict__ Vpre, const float* __restrict__ O,
                                                   const float* const* __restrict__ orth, float* __restrict__ u_out,
                                                   float* __restrict__ Hu_out, float* __restrict__ ux_out,
@@ -102,11 +102,11 @@ __global__ __launch_bounds__(256) void k_head_pde(Phys ph, float base_norm, Pts 
                                                   const float* __restrict__ bc_target, float* __restrict__ Ob,
                                                   double* __restrict__ lsums) {
     constexpr int D = C - 1 - E;
-    __shared__ double red[4];
+    __shared__ double red[16];
     double num = 0.0, den = 0.0, so[GPE_MAX_ORTH] = {0.0, 0.0, 0.0, 0.0};
     double rzk = 0.0, rzp = 0.0, rzi = 0.0, rzl = 0.0, bse = 0.0;
     // grid-stride: few workgroups, one double atomic each per sum (same-address atomics serialise at ~25 ns apiece)
-    for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < N; m += (int64_t)gridDim.x * 256) {
+    for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < N; m += (int64_t)gridDim.x * blockDim.x) {
         float xv[3] = {0.f, 0.f, 0.f};
         for (int k = 0; k < ph.dim; ++k) xv[k] = pts_at(x, m, ph.dim, k);
         if (m >= n_pde) {                              // boundary point riding in this batch
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void k_head_pde(Phys ph, float base_norm, Pts 
 // ---- phase 2: residual + seeds -------------------------------------------------------------------
 // lambda = num/den (global sums), r = Hu - lambda u, sum r^2 -> gtail[GT_SUM_R2]; Ob = dLoss/dO.
 template <int C, int E>
-__global__ __launch_bounds__(256) void k_seed_pde(Phys ph, Pts x, const float* __restrict__ Vpre,
+__global__ __launch_bounds__(1024) void k_seed_pde(Phys ph, Pts x, const float* __restrict__ Vpre,
                                                   const float* const* __restrict__ orth,
                                                   const float* __restrict__ u_in, const float* __restrict__ Hu_in,
                                                   const float* __restrict__ ux_in,
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void k_seed_pde(Phys ph, Pts x, const float* _
                                                   int64_t ld, int want_seeds, const double* __restrict__ slots, int nslots,
                                                   double* __restrict__ sums_out, double* __restrict__ lsums_out) {
     constexpr int D = C - 1 - E;
-    __shared__ double red[4];
+    __shared__ double red[16];
     double sr2 = 0.0;
     double num, den;
     if (slots) {      // the forward kernel ran the head (HeadArgs) and left one (num, den, bse) triple per workgroup: add them in a fixed tree
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void k_seed_pde(Phys ph, Pts x, const float* _
             if (tot[2] != 0.0) atomicAdd(&lsums_out[LS_BC_SE2], tot[2]);
         }
     } else { num = sums[S_NUM]; den = sums[S_DEN]; }
-    for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < N; m += (int64_t)gridDim.x * 256) {
+    for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < N; m += (int64_t)gridDim.x * blockDim.x) {
         float lam = (float)(num / den);
         float I = (float)den * ph.dx;
         float xv[3] = {0.f, 0.f, 0.f};
