@@ -539,7 +539,18 @@ def main():
             out.pop("roofline_forward", None)
         if world == 1 and fused and not args.no_alt_mode and max(layers[1:-1]) <= 64 and not os.environ.get("GPE_FWD_B6") \
                 and not os.environ.get("GPE_BWD_B6"):
-            out["split_bf16_mode"] = split_bf16_mode(cfg, flat, x, xb, local_rank, args, n_local)
+            out["split_bf16_mode"] = alt = split_bf16_mode(cfg, flat, x, xb, local_rank, args, n_local)
+            # its accounting, over the WHOLE step (no per-kernel events in this pass): the hidden-hidden products of the forward pass and
+            # the adjoint products of the reverse pass run as six bf16 products each (executed bf16 MFMA FLOP = 6 x their fp32 FLOP,
+            # against the 2.5 PFLOP/s dense bf16 peak); the weight-gradient products stay on the fp32 instruction (157.3 TFLOP/s)
+            hh = chan * 2.0 * Hh * Hh * (Lh - 1)                      # fp32 FLOP per point of the hidden-hidden products of ONE pass direction
+            alt["accounting"] = {"bf16_mfma_flop_per_point": 6.0 * 2.0 * hh, "fp32_mfma_flop_per_point": hh,
+                                 "bf16_mfma_tflops_whole_step": 6.0 * 2.0 * hh * alt["value"] / 1e12, "bf16_peak_tflops": 2500.0,
+                                 "bf16_frac_whole_step": 6.0 * 2.0 * hh * alt["value"] / 1e12 / 2500.0,
+                                 "fp32_mfma_tflops_whole_step": hh * alt["value"] / 1e12,
+                                 "fp32_frac_whole_step": hh * alt["value"] / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                 "pipe_time_frac_whole_step": 6.0 * 2.0 * hh * alt["value"] / 1e12 / 2500.0 + hh * alt["value"] / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                 "note": "fractions of each pipe's peak summed = share of the step the matrix pipes are busy at peak rates"}
         if world == 1 and not args.no_parity_check:
             big = (max(layers[1:-1]) > 64) or (len(layers) > 7)
             out["parity_check"] = parity_check(eng, wl, flat, x, dx, xb, 4096 if big else 65536, n_local * world)
