@@ -35,8 +35,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")
-PROFILE_DIR_PREV = os.path.join(ROOT, "profiles", "r02")
+PROFILE_ROUND, PROFILE_ROUND_PREV = "r04", "r03"
+PROFILE_DIR = os.path.join(ROOT, "profiles", PROFILE_ROUND)
+PROFILE_DIR_PREV = os.path.join(ROOT, "profiles", PROFILE_ROUND_PREV)
 
 WORKLOADS = {
     # name: layers, per-GPU grid (weak scaling), global grid of the BASELINE config (strong scaling), gamma, domain half-width
@@ -229,14 +230,16 @@ def launch_workers(args):
 
 
 def load_profile_json(name):
-    for d in (PROFILE_DIR, PROFILE_DIR_PREV):            # this round's record, else the previous round's (the path is reported)
+    """-> (record, path, stale): this round's committed record, else the previous round's -- then `stale` names that round, and the
+    line labels every figure taken from it as coming from an earlier build."""
+    for d, rnd in ((PROFILE_DIR, None), (PROFILE_DIR_PREV, PROFILE_ROUND_PREV)):
         p = os.path.join(d, name)
         if os.path.exists(p):
             try:
-                return json.load(open(p)), os.path.relpath(p, ROOT)
+                return json.load(open(p)), os.path.relpath(p, ROOT), rnd
             except Exception:
                 pass
-    return None, None
+    return None, None, None
 
 
 def split_bf16_mode(cfg, flat, x, xb, local_rank, args, n_local):
@@ -273,31 +276,53 @@ def split_bf16_mode(cfg, flat, x, xb, local_rank, args, n_local):
                     "about 9 % lower clocks in this mode (power limit)"}
 
 
-def parity_check(eng, wl, flat, x, dx, xb, n_check, world_pts):
+def parity_points(layers, n_local, budget_s):
+    """Points the in-run oracle check covers: the whole bound batch (the launch configuration that was TIMED: uneven tile split,
+    head inside the forward kernel) when the numpy oracle fits the time budget, else the largest slice that does (>= 4096).  Cost
+    model measured on the GPU box's host: ~4.5e-9 s per (parameter x point) for the two-phase sharded oracle."""
+    P = sum(layers[i] * layers[i + 1] + layers[i + 1] for i in range(len(layers) - 1))
+    n_fit = int(budget_s / (4.5e-9 * P))
+    if n_fit >= n_local:
+        return n_local
+    return max(4096, min(n_local, n_fit // 4096 * 4096))
+
+
+def parity_check(eng, wl, flat, x, dx, xb, n_check, world_pts, timed_kernels):
     """Correctness evidence measured in this process, after the timed region, on the bench engine itself: its parameters and
-    optimiser are reset, a slice of the same points is bound, ONE step runs, and loss, mu and the gradient are compared with the
-    fp64 oracle (oracle/gpe_oracle.py -- the checker, never the thing measured) on that slice.  The engine is left on the slice."""
+    optimiser are reset, ONE step runs on the bound batch AS TIMED (or, for the workloads whose oracle would take minutes, on a slice
+    of the same points), and loss, mu and the gradient are compared with the fp64 oracle (oracle/gpe_oracle.py -- the checker, never
+    the thing measured; sharded two-phase evaluation over 65 536-point chunks)."""
     from oracle import gpe_oracle as go
-    idx = np.linspace(0, x.shape[0] - 1, n_check).astype(np.int64)
-    xs = np.ascontiguousarray(x[idx])
+    full = n_check >= x.shape[0]
+    if full:
+        xs = x
+    else:
+        idx = np.linspace(0, x.shape[0] - 1, n_check).astype(np.int64)
+        xs = np.ascontiguousarray(x[idx])
     pb = oracle_problem(wl, dx)
     t0 = time.perf_counter()
-    osc, ograd, _ = go.full_loss_and_grad(pb, flat.astype(np.float64), xs.astype(np.float64), xb.astype(np.float64))
+    osc, ograd = go.sharded_loss_and_grad(pb, flat.astype(np.float64), xs.astype(np.float64), xb.astype(np.float64),
+                                          chunk=65536, threads=min(8, os.cpu_count() or 1))
     t_or = time.perf_counter() - t0
     eng.set_params(flat)
     eng.reset_optimizer(1e-3)
-    eng.bind_points(torch.as_tensor(xs, device=f"cuda:{eng.device}"))
-    eng.set_n_global(n_check)
+    if not full:
+        eng.bind_points(torch.as_tensor(xs, device=f"cuda:{eng.device}"))
+        eng.set_n_global(n_check)
     kernels = eng.active_kernels
     sc = eng.step()
     g = eng.get_grad()
     gerr = float(np.abs(g - ograd).max() / np.abs(ograd).max())
-    res = {"points": int(n_check), "oracle": "oracle/gpe_oracle.py (numpy fp64), same seeded weights, same points", "kernels": kernels,
+    res = {"points": int(xs.shape[0]), "batch": "the bound batch as timed" if full else f"{n_check}-point slice of the timed batch",
+           "oracle": "oracle/gpe_oracle.py (numpy fp64, sharded two-phase evaluation), same seeded weights, same points",
+           "kernels": kernels, "timed_kernels": timed_kernels, "same_kernels_as_timed": kernels == timed_kernels,
+           "uneven_split": kernels.get("split", "") not in ("", "fwd 0/1024, bwd 0/1024"),
            "loss": sc["loss"], "loss_oracle": float(osc["loss"]), "loss_rel_err": abs(sc["loss"] - osc["loss"]) / abs(osc["loss"]),
            "mu": sc["mu"], "mu_oracle": float(osc["mu"]), "mu_rel_err": abs(sc["mu"] - osc["mu"]) / abs(osc["mu"]),
            "grad_max_err_over_max_abs": gerr, "tolerance": {"loss_rel": 1e-4, "mu_rel": 2e-5, "grad": 5e-5}, "oracle_seconds": t_or}
     res["ok"] = bool(res["loss_rel_err"] < 1e-4 and res["mu_rel_err"] < 2e-5 and gerr < 5e-5)
-    eng.set_n_global(world_pts)
+    if not full:
+        eng.set_n_global(world_pts)
     return res
 
 
@@ -337,6 +362,9 @@ def main():
                          "reports the median block, min and max.  Shortened automatically when 50 blocks would exceed ~20 s")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="launcher (--gpus N): overall limit in seconds")
     ap.add_argument("--no-parity-check", action="store_true")
+    ap.add_argument("--parity-points", type=int, default=0,
+                    help="points of the in-run oracle check; 0 = the whole timed batch when the oracle fits --parity-budget, else a slice")
+    ap.add_argument("--parity-budget", type=float, default=90.0, help="seconds of host time the in-run oracle check may take")
     ap.add_argument("--exchange", default="engine", choices=["engine", "torch"],
                     help="N > 1: all-reduces issued by the engine (native RCCL) or by torch.distributed between the phases")
     ap.add_argument("--async-grad", action="store_true",
@@ -476,7 +504,7 @@ def main():
         # HBM bytes per launch of the dominant kernel and the SQ counter shares: from the committed rocprofv3 --pmc passes of
         # this same command (tools/profile_round.sh); never measured in this process -> always labelled "from_profile"
         traffic, traffic_src, util = None, None, None
-        tj, tsrc = load_profile_json(f"traffic_{args.workload}.json")
+        tj, tsrc, tstale = load_profile_json(f"traffic_{args.workload}.json")
         if tj:
             ks = tj.get("kernels", {})
             if "w_bwd_map" in kernels["bwd"]:       # the reverse pass is several launches: bytes of ONE pass = sum over its launches
@@ -489,11 +517,12 @@ def main():
                     if "f_backward" in k and (traffic is None or v["hbm_bytes_per_point"] * n_rows > traffic):
                         traffic = v["hbm_bytes_per_point"] * n_rows
             if traffic is not None:
-                traffic_src = f"from_profile: {tsrc} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 1/2-fetch correction)"
-        uj, usrc = load_profile_json(f"mfma_util_{args.workload}.json")
+                traffic_src = f"from_profile: {tsrc} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 1/2-fetch correction)" + \
+                              (f" -- STALE: recorded on the {tstale} build" if tstale else "")
+        uj, usrc, ustale = load_profile_json(f"mfma_util_{args.workload}.json")
         if uj:
-            util = dict(uj, source=f"from_profile: {usrc}")
-        aj, asrc = load_profile_json(f"accuracy_{args.workload}.json")
+            util = dict(uj, source=f"from_profile: {usrc}" + (f" -- STALE: recorded on the {ustale} build" if ustale else ""))
+        aj, asrc, astale = load_profile_json(f"accuracy_{args.workload}.json")
         out = {
             "metric": "collocation-point residual evals/sec (full training step: jets fwd + residual + reverse + Adam)",
             "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -515,6 +544,7 @@ def main():
                                    "converged accuracy is mu_abs_err (tools/accuracy_nd.py), the correctness of the kernels parity_check"},
             "mu_abs_err": (aj or {}).get("mu_abs_err"), "mu_ref": (aj or {}).get("mu_ref"),
             "mu_abs_err_source": f"from_profile: {asrc} (converged run of tools/accuracy_nd.py vs oracle/gp_ground_state_nd.py)" if aj else None,
+            "mu_abs_err_round": (f"{astale} (stale: a converged run of the previous round's build)" if astale else PROFILE_ROUND) if aj else None,
             "roofline": {"bound": "mfma", "kernel": kernels["bwd"],
                          "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP32_MFMA_PEAK_TFLOPS, "frac_gemm_only": ach_gemm / FP32_MFMA_PEAK_TFLOPS,
@@ -552,8 +582,8 @@ def main():
                                  "pipe_time_frac_whole_step": 6.0 * 2.0 * hh * alt["value"] / 1e12 / 2500.0 + hh * alt["value"] / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                                  "note": "fractions of each pipe's peak summed = share of the step the matrix pipes are busy at peak rates"}
         if world == 1 and not args.no_parity_check:
-            big = (max(layers[1:-1]) > 64) or (len(layers) > 7)
-            out["parity_check"] = parity_check(eng, wl, flat, x, dx, xb, 4096 if big else 65536, n_local * world)
+            n_chk = args.parity_points if args.parity_points > 0 else parity_points(layers, n_local, args.parity_budget)
+            out["parity_check"] = parity_check(eng, wl, flat, x, dx, xb, min(n_chk, n_local), n_local * world, kernels)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, flat)
             out["cpu_baseline_native"] = cpu_baseline_native(wl, flat)

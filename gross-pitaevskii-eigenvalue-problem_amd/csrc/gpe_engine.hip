@@ -1209,7 +1209,17 @@ int gpe_active_kernels(gpe_engine* e, char* buf, size_t n) {
         snprintf(r, sizeof r, "%s<%d,%d>", (e->gen_mfma && e->gen_mfma2 && W % 128 == 0) ? "g_bwd_weight_mfma2"
                                             : (m1 ? "g_bwd_weight_mfma" : "g_bwd_weight"), b.C, b.E);
     }
-    snprintf(buf, n, "fwd=%s;bwd=%s", f, r);
+    // uneven static tile split between the two workgroups of a CU (large batches; launch_f_forward / launch_coop_no apply the same rules)
+    int sf = 0, sb = 0;
+    if (e->path == GPE_PATH_FUSED && !e->wide && e->H <= 64) {
+        const int64_t ntiles = (b.n + 15) / 16, g2 = 2 * (int64_t)e->num_cu;
+        if (!fwd_coop(e, b) && !e->fwd_b6 && e->fwd_share > 0 && fused_grid(e, b.n, 4, 2) == (unsigned)g2 && ntiles >= 4 * e->share_min_tiles * g2)
+            sf = e->fwd_share;
+        if (bwd_kind(e, b) == 3 && use_pipe(e, b.C) && !seed_in_reverse(e) && e->pipe_share > 0 &&
+            fused_grid(e, b.n, 1, e->coop_wg_per_cu) == (unsigned)g2 && ntiles >= e->share_min_tiles * g2)
+            sb = e->pipe_share;
+    }
+    snprintf(buf, n, "fwd=%s;bwd=%s;split=fwd %d/1024, bwd %d/1024", f, r, sf, sb);
     return GPE_OK;
 }
 
@@ -1689,18 +1699,23 @@ int gpe_step_begin(gpe_engine* e) {
     if (e->cfg.base_mode >= 0 && e->cfg.base_kind == GPE_BASE_PRECOMPUTED && !e->orth_host[4])
         FAIL(e, GPE_ERR_STATE, "precomputed base requested but gpe_bind_base was not called");
     int rc;
+    e->fh_now = false; e->seedf_now = false;      // per-step flags: a step that failed half-way must not leave them behind
+    e->phase = 0;
     if ((rc = launch_begin(e))) return rc;
     if ((rc = bc_fork(e, true))) return rc;
-    e->fh_now = head_in_forward(e);
-    if (e->fh_now) e->fh_nslots = (int)(head_fusable_coop(e) ? fused_grid(e, e->main.n, 1, 2) : fused_grid(e, e->main.n, 4, 2));
-    if ((rc = mlp_forward(e, e->main, true))) { e->fh_now = false; return rc; }
-    if (!e->fh_now && (rc = launch_head_pde(e))) return rc;
-    if (e->cfg.w_sym != 0.f) {
-        if ((rc = mlp_forward(e, e->sym, true))) return rc;
-        hipLaunchKernelGGL(k_head_sym, dim3(cdiv(e->n_pde, 256)), dim3(256), 0, e->stream, e->ph, e->sym.O, e->sums(),
-                           e->n_pde, e->sym.ld);
-        HIPCHK(e, hipGetLastError());
+    const bool fh = head_in_forward(e);
+    if (fh) e->fh_nslots = (int)(head_fusable_coop(e) ? fused_grid(e, e->main.n, 1, 2) : fused_grid(e, e->main.n, 4, 2));
+    e->fh_now = fh;
+    rc = mlp_forward(e, e->main, true);
+    if (!rc && !fh) rc = launch_head_pde(e);
+    if (!rc && e->cfg.w_sym != 0.f) {
+        if (!(rc = mlp_forward(e, e->sym, true))) {
+            hipLaunchKernelGGL(k_head_sym, dim3(cdiv(e->n_pde, 256)), dim3(256), 0, e->stream, e->ph, e->sym.O, e->sums(),
+                               e->n_pde, e->sym.ld);
+            if (hipGetLastError() != hipSuccess) { e->err = "k_head_sym launch failed"; rc = GPE_ERR_HIP; }
+        }
     }
+    if (rc) { e->fh_now = false; return rc; }
     e->phase = 1;
     return GPE_OK;
 }
@@ -1819,6 +1834,7 @@ int gpe_mse_begin(gpe_engine* e) {
     if (!e) return GPE_ERR_INVALID;
     if (!e->mse_target || e->mse.n <= 0) FAIL(e, GPE_ERR_STATE, "mse step before bind_target");
     int rc;
+    e->fh_now = false; e->seedf_now = false;
     e->mse.pts = Pts{e->ux, nullptr, e->n_pde};
     if ((rc = launch_begin(e))) return rc;
     if ((rc = mlp_forward(e, e->mse, true))) return rc;
@@ -1961,6 +1977,22 @@ static int dp_join(gpe_engine* e) {       // the compute stream continues after 
     return GPE_OK;
 }
 
+// First phase of an engine-driven data-parallel step: as in gpe_step nobody reads the step sums between the passes, so the forward
+// kernel may run the head (the N = 1 kernels: no k_head_pde); its per-workgroup triples are added by one small launch into the sums
+// the first all-reduce exchanges, and the reverse phase then reads the GLOBAL sums like after k_head_pde.
+static int dp_begin(gpe_engine* e) {
+    e->fh_want = true;
+    int rc = gpe_step_begin(e);
+    e->fh_want = false;
+    if (rc) return rc;
+    if (e->fh_now) {
+        hipLaunchKernelGGL(k_slots_to_sums, dim3(1), dim3(64), 0, e->stream, (const double*)e->head_slots, e->fh_nslots, e->sums(), e->lsums());
+        HIPCHK(e, hipGetLastError());
+        e->fh_now = false;                          // consumers take the (all-reduced) sums, not the local slots
+    }
+    return GPE_OK;
+}
+
 // One synchronous data-parallel step, no host synchronisation: begin -> all-reduce of the 12 double sums -> backward with the
 // gradient all-reduced on the exchange stream (generic set: one bucket per linear map, output map first, behind the remaining
 // reverse pass; fused set: the reverse pass is a single kernel, so one P+4 message) -> clip/Adam (replicated, bit-identical).
@@ -1975,7 +2007,7 @@ static int step_dp_async(gpe_engine* e) {
     e->grad = gcur;                                   // this step's buffer: zeroed by k_begin (generic set), written by the reverse pass;
                                                       // the other one holds g_{t-1} until this step's update has applied it
     e->acc_clean = e->acc_clean && e->path == GPE_PATH_FUSED;
-    rc = gpe_step_begin(e);
+    rc = dp_begin(e);
     if (!rc) rc = dp_allreduce_after(e, e->sums(), S_COUNT, ncclDouble, e->ev_x0);
     if (!rc) rc = dp_join(e);
     if (!rc) rc = gpe_step_backward(e);
@@ -2026,7 +2058,7 @@ int gpe_step_dp(gpe_engine* e) {
     if (!e->comm) FAIL(e, GPE_ERR_STATE, "gpe_step_dp before gpe_comm_init");
     if (e->async_grad) return step_dp_async(e);
     int rc;
-    if ((rc = gpe_step_begin(e))) return rc;
+    if ((rc = dp_begin(e))) return rc;
     if ((rc = dp_allreduce_after(e, e->sums(), S_COUNT, ncclDouble, e->ev_x0))) return rc;
     if ((rc = dp_join(e))) return rc;
     // layer buckets need every map's gradient to be final when its weight kernel ends: no second batch adding to it later
@@ -2170,6 +2202,7 @@ int gpe_residual(gpe_engine* e, gpe_scalars* out, float* d_psi, float* d_resid) 
     if (!e || !out) return GPE_ERR_INVALID;
     if (e->main.n <= 0) FAIL(e, GPE_ERR_STATE, "residual before bind_points");
     int rc;
+    e->fh_now = false; e->seedf_now = false;      // forward-only evaluation: k_head_pde forms the sums, never the slots of an earlier step
     if ((rc = launch_begin(e, /*force=*/true))) return rc;      // no reverse pass here: the gradient buffer must read zero
     if ((rc = mlp_forward(e, e->main, false))) return rc;
     if ((rc = launch_head_pde(e))) return rc;

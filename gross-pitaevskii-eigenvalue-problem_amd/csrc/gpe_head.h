@@ -209,6 +209,34 @@ __global__ __launch_bounds__(1024) void k_head_pde(Phys ph, float base_norm, Pts
     }
 }
 
+// Data-parallel steps whose forward kernel ran the head (HeadArgs): the per-workgroup (num, den, bse) triples are added here -- same
+// fixed tree as the consumers below use, so the local sums are the single-GPU sums bit for bit -- and filed in sums / lsums, where the
+// all-reduce of the step sums picks them up.  One wave.
+__global__ __launch_bounds__(64) void k_slots_to_sums(const double* __restrict__ slots, int nslots, double* __restrict__ sums,
+                                                      double* __restrict__ lsums) {
+    double sv[8][3];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int b = threadIdx.x + 64 * k;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) sv[k][i] = b < nslots ? slots[(size_t)b * 4 + i] : 0.0;
+    }
+    double t3[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) t3[i] += sv[k][i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) t3[i] += __shfl_xor(t3[i], o, 64);
+    }
+    if (threadIdx.x == 0) {
+        sums[S_NUM] = t3[0]; sums[S_DEN] = t3[1];
+        if (t3[2] != 0.0) lsums[LS_BC_SE2] += t3[2];
+    }
+}
+
 // ---- phase 2: residual + seeds -------------------------------------------------------------------
 // lambda = num/den (global sums), r = Hu - lambda u, sum r^2 -> gtail[GT_SUM_R2]; Ob = dLoss/dO.
 template <int C, int E>

@@ -119,6 +119,31 @@ def _check_dev_f32(t: torch.Tensor, name: str):
         raise ValueError(f"{name} must be a contiguous float32 tensor on the GPU")
 
 
+def _store_get(store, key, timeout, rank):
+    """ncclUniqueId from a key-value store, bounded in time: a rank whose key never appears (ranks that created a different number
+    of communicators look up different default keys) must fail with the key's name instead of blocking for ever."""
+    import time
+    if hasattr(store, "wait"):                           # torch.distributed stores: a wait with its own timeout
+        import datetime
+        try:
+            store.wait([key], datetime.timedelta(seconds=timeout))
+        except Exception as ex:
+            raise TimeoutError(f"comm_init: rank {rank} found no ncclUniqueId under store key {key!r} within {timeout:.0f} s "
+                               f"(does every rank create its communicators in the same order / publish under this key?)") from ex
+        return bytes(store.get(key))
+    deadline = time.monotonic() + timeout
+    while True:
+        try:
+            v = store.get(key)
+        except KeyError:
+            v = None
+        if v is not None:
+            return bytes(v)
+        if time.monotonic() > deadline:
+            raise TimeoutError(f"comm_init: rank {rank} found no ncclUniqueId under store key {key!r} within {timeout:.0f} s")
+        time.sleep(0.01)
+
+
 class Engine:
     """One engine per process per GPU.  The HIP extension is mandatory (no fallback)."""
 
@@ -185,12 +210,14 @@ class Engine:
     # ---- data-parallel exchange inside the engine (RCCL on the engine's exchange stream) ---------------------------------
     _comm_seq = 0          # communicators created by this process: every rank creates them in the same order
 
-    def comm_init(self, rank: int, world: int, store=None, key: str = "gpe_comm_id"):
+    def comm_init(self, rank: int, world: int, store=None, key: str = None, timeout: float = 300.0):
         """Create the engine's own RCCL communicator.  The 128-byte ncclUniqueId of rank 0 reaches the other ranks through
-        `store` (anything with set / get; the key is unique per communicator -- `key`/<sequence number> -- so a second engine, or a
-        communicator re-created after comm_destroy, never reads the id of an earlier one) or, when none is given, by
-        torch.distributed.broadcast_object_list over the initialised default group."""
-        key = f"{key}/{Engine._comm_seq}"
+        `store` (anything with set / get) or, when none is given, by torch.distributed.broadcast_object_list over the initialised
+        default group.  `key`: the FULL store key, used as given (non-Python ranks can publish / read it under the same name); left
+        at None it is "gpe_comm_id/<n>", n = communicators this process has created so far -- every rank must then create its
+        communicators in the same order.  A rank that does not find the id within `timeout` seconds raises, naming the key."""
+        if key is None:
+            key = f"gpe_comm_id/{Engine._comm_seq}"
         Engine._comm_seq += 1
         ident = (C.c_ubyte * capi.GPE_COMM_ID_BYTES)()
         if rank == 0:
@@ -199,7 +226,7 @@ class Engine:
             if rank == 0:
                 store.set(key, bytes(ident))
             else:
-                C.memmove(ident, bytes(store.get(key)), capi.GPE_COMM_ID_BYTES)
+                C.memmove(ident, _store_get(store, key, timeout, rank), capi.GPE_COMM_ID_BYTES)
         elif world > 1:                                    # default: the initialised torch.distributed group, public API only
             import torch.distributed as dist
             box = [bytes(ident) if rank == 0 else None]

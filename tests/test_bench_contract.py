@@ -129,4 +129,6 @@ def test_bench_line_contract():
     assert t["blocks"] >= 5 and t["steps_per_block"] == 3 and t["ms_per_step_min"] <= d["ms_per_step"] <= t["ms_per_step_max"]
     pc = d["parity_check"]
     assert pc["ok"] is True and pc["grad_max_err_over_max_abs"] < 5e-5 and pc["mu_rel_err"] < 2e-5, pc
+    # ... taken on the batch AS TIMED, through the kernels that were timed (not on a slice with another launch configuration)
+    assert pc["points"] == d["config"]["points_per_gpu"] and pc["same_kernels_as_timed"] is True, pc
     assert "mu_after_timed_steps" not in d and "trajectory" in d

@@ -63,3 +63,19 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f"{f} imports the oracle"
                 assert "gpe_oracle" not in src and "torch_ref" not in src, f"{f} references the oracle"
+
+
+def test_comm_id_lookup_is_bounded_and_names_the_key():
+    """ranks that created a different number of communicators look up different default keys; the lookup of the
+    ncclUniqueId must time out with the key's name, and a caller-supplied key must be used as given."""
+    from gpe_pinn import engine
+
+    class Store(dict):
+        def set(self, k, v): self[k] = v
+        def get(self, k): return self[k]
+
+    st = Store()
+    with pytest.raises(TimeoutError, match="gpe_comm_id/7"):
+        engine._store_get(st, "gpe_comm_id/7", 0.05, rank=1)
+    st.set("my/key", b"x" * 128)
+    assert engine._store_get(st, "my/key", 0.05, rank=1) == b"x" * 128

@@ -681,6 +681,30 @@ def test_uneven_tile_split_of_large_batches_changes_nothing_but_the_order():
         assert H.rel_err(g, out[0][2]) < 3e-6
 
 
+def test_large_batch_launch_configuration_against_the_oracle():
+    """The launch configuration of the headline run -- uneven tile split between the two workgroups of a CU in f_forward and
+    f_backward_pipe, head inside the forward kernel, k_seed_pde adding the per-workgroup triples -- against the fp64 ORACLE itself
+    (sharded two-phase evaluation), not against another kernel variant: 540 000 points (ragged last tile), one step."""
+    import os
+    kw = dict(layers=[2, 64, 64, 64, 64, 1], gamma=50.0, dx=0.01)
+    N = 540000
+    scale = _scale(kw)
+    x, flat, x_bc = _inputs(kw, N, scale=scale)
+    pb = go.Problem(**kw)
+    eng = make_engine(pb, flat, x, x_bc)
+    k = eng.active_kernels
+    if not any(v in os.environ for v in ("GPE_PIPE_SHARE", "GPE_FWD_SHARE", "GPE_FUSE_HEAD", "GPE_FWD_B6", "GPE_PIPE", "GPE_COOP")):
+        assert k["fwd"].endswith(",head>") and "f_backward_pipe" in k["bwd"] and k["split"] == "fwd 640/1024, bwd 576/1024", k
+    sc = eng.step()
+    g = eng.get_grad()
+    eng.close()
+    osc, ograd = go.sharded_loss_and_grad(pb, flat.astype(np.float64), x.astype(np.float64),
+                                          None if x_bc is None else x_bc.astype(np.float64), chunk=65536, threads=8)
+    assert abs(sc["loss"] - osc["loss"]) <= 1e-4 * abs(osc["loss"]), (sc["loss"], osc["loss"])
+    assert abs(sc["mu"] - osc["mu"]) <= 2e-5 * abs(osc["mu"]), (sc["mu"], osc["mu"])
+    assert H.rel_err(g, ograd) < 5e-5
+
+
 @pytest.mark.parametrize("layers,sym,sched", [([1, 32, 32, 32, 32, 1], 5.0, go.SCHED_PLATEAU), ([1, 64, 64, 64, 1], 0.0, go.SCHED_COSINE_LOSS),
                                               ([2, 64, 64, 64, 64, 1], 0.0, go.SCHED_CONST)])
 def test_update_kernel_forms_are_bit_identical(layers, sym, sched):

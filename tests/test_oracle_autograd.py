@@ -128,3 +128,19 @@ def test_orthogonality_definition_and_dp_additivity():
     gsum = r2[0]["grad_local"] + r2[1]["grad_local"] + r2[0]["grad_bc"]
     assert np.abs(gsum - g).max() <= 1e-12 * np.abs(g).max()
     assert abs(r2[0]["L_orth"] - sc["orth"]) <= 1e-13 * sc["orth"]
+
+
+def test_sharded_two_phase_oracle_equals_the_single_call():
+    """oracle.sharded_loss_and_grad (what bench.py's in-run parity_check and the 540 000-point GPU test run on the batch as timed):
+    chunked two-phase evaluation == one call on the whole batch, to the order of the fp64 sums."""
+    rng = np.random.default_rng(5)
+    layers = [2, 32, 32, 32, 1]
+    pb = go.Problem(layers=layers, gamma=300.0, p=3, kinetic_coeff=0.5, pot_scale=0.5, dx=2e-3, w_bc=10.0, w_norm=20.0)
+    x = rng.uniform(-4, 4, (3001, 2))
+    xb = rng.uniform(-4, 4, (17, 2))
+    flat = rng.normal(0, 0.3, go.param_count(layers))
+    sc, g, _ = go.full_loss_and_grad(pb, flat, x, xb)
+    sc2, g2 = go.sharded_loss_and_grad(pb, flat, x, xb, chunk=700, threads=3)
+    for k in ("loss", "pde", "bc", "norm", "mu"):
+        assert abs(sc[k] - sc2[k]) <= 1e-12 * max(1.0, abs(sc[k])), k
+    assert np.abs(g - g2).max() <= 1e-12 * np.abs(g).max()
