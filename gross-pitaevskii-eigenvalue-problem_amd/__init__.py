@@ -14,5 +14,9 @@ from ._capi import (ACT_TANH, ACT_TANH_PLUS1, POT_GAUSSIAN, POT_HARMONIC, POT_NO
 from .engine import Engine, GPEConfig, GPEError
 from . import dp, surface, checkpoint, relobralo
 from .surface import refine, refine_negative, notebook, box, gravity_well, box_to_gaussian
+from .surface import vary_beta_harmonic, vary_beta_gravity_well, vary_beta_box_and_gaussian
 
-__all__ = ["capi", "Engine", "GPEConfig", "GPEError", "dp", "surface", "checkpoint", "refine", "refine_negative", "notebook", "box", "gravity_well", "box_to_gaussian"]
+vary_beta = vary_beta_harmonic      # refine/vary_potential_parameter_harmonic.py, the flavour SURVEY 8(f3) cites
+
+__all__ = ["capi", "Engine", "GPEConfig", "GPEError", "dp", "surface", "checkpoint", "refine", "refine_negative", "notebook", "box", "gravity_well", "box_to_gaussian",
+           "vary_beta", "vary_beta_harmonic", "vary_beta_gravity_well", "vary_beta_box_and_gaussian"]

@@ -447,6 +447,7 @@ struct gpe_engine {
     int64_t async_t = 0;
     bool dp_bucket = false;                           // set by gpe_step_dp: the generic reverse pass hands finished layers to the comm stream
     int64_t dp_collectives = 0;                       // all-reduces issued since gpe_comm_init (bench / tests)
+    bool dp_inline = true;                            // synchronous step on the fused / wide sets: collectives on the compute stream (GPE_DP_INLINE=0: exchange stream)
     int phase = 0;                 // 0 idle, 1 after begin, 2 after backward
     std::string err;
     double* sums() { return dbl; }
@@ -1928,6 +1929,7 @@ int gpe_comm_init(gpe_engine* e, const void* id128, int rank, int world) {
     memcpy(&id, id128, sizeof id);
     RCCLCHK(e, e->rccl.CommInitRank(&e->comm, world, id, rank));
     e->comm_rank = rank; e->comm_world = world;
+    { const char* envi = getenv("GPE_DP_INLINE"); e->dp_inline = !(envi && atoi(envi) == 0); }
     HIPCHK(e, hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
     HIPCHK(e, hipEventCreateWithFlags(&e->ev_x0, hipEventDisableTiming));
     HIPCHK(e, hipEventCreateWithFlags(&e->ev_x1, hipEventDisableTiming));
@@ -1968,6 +1970,11 @@ static int dp_allreduce_after(gpe_engine* e, void* buf, size_t count, ncclDataTy
     HIPCHK(e, hipEventRecord(ev, e->stream));
     HIPCHK(e, hipStreamWaitEvent(e->comm_stream, ev, 0));
     RCCLCHK(e, e->rccl.AllReduce(buf, buf, count, dt, ncclSum, e->comm, e->comm_stream));
+    e->dp_collectives++;
+    return GPE_OK;
+}
+static int dp_allreduce_inline(gpe_engine* e, void* buf, size_t count, ncclDataType_t dt) {     // ... on the compute stream itself
+    RCCLCHK(e, e->rccl.AllReduce(buf, buf, count, dt, ncclSum, e->comm, e->stream));
     e->dp_collectives++;
     return GPE_OK;
 }
@@ -2059,18 +2066,26 @@ int gpe_step_dp(gpe_engine* e) {
     if (e->async_grad) return step_dp_async(e);
     int rc;
     if ((rc = dp_begin(e))) return rc;
-    if ((rc = dp_allreduce_after(e, e->sums(), S_COUNT, ncclDouble, e->ev_x0))) return rc;
-    if ((rc = dp_join(e))) return rc;
     // layer buckets need every map's gradient to be final when its weight kernel ends: no second batch adding to it later
-    e->dp_bucket = e->path == GPE_PATH_GENERIC && e->cfg.w_sym == 0.f && !e->bc_inflight;
+    const bool bucketed = e->path == GPE_PATH_GENERIC && e->cfg.w_sym == 0.f && !e->bc_inflight;
+    // Fused / wide kernel sets: the next kernel needs each all-reduce's result at once and nothing else is enqueued meanwhile, so the
+    // collective goes onto the COMPUTE stream itself -- no event hop to the exchange stream and back (each cross-stream dependency
+    // costs several microseconds on this runtime: 4 hops were most of the 35-40 us a world-1 step lost against the plain step,
+    // profiles/r04/dp_world1_*.json).  The exchange stream stays for what does overlap: the generic set's layer buckets and the
+    // opt-in stale-gradient mode.  GPE_DP_INLINE=0 restores the two-stream form.
+    const bool inl = !bucketed && e->dp_inline;
+    if (inl) rc = dp_allreduce_inline(e, e->sums(), S_COUNT, ncclDouble);
+    else if (!(rc = dp_allreduce_after(e, e->sums(), S_COUNT, ncclDouble, e->ev_x0))) rc = dp_join(e);
+    if (rc) return rc;
+    e->dp_bucket = bucketed;
     rc = gpe_step_backward(e);
-    const bool bucketed = e->dp_bucket;
     e->dp_bucket = false;
     if (rc) return rc;
     if (bucketed) rc = dp_allreduce_after(e, e->grad + e->P, GT_COUNT, ncclFloat, e->ev_x0);      // exchange tail (sum r^2)
+    else if (inl) rc = dp_allreduce_inline(e, e->grad, (size_t)e->P + GT_COUNT, ncclFloat);
     else rc = dp_allreduce_after(e, e->grad, (size_t)e->P + GT_COUNT, ncclFloat, e->ev_x0);
     if (rc) return rc;
-    if ((rc = dp_join(e))) return rc;
+    if (!inl && (rc = dp_join(e))) return rc;
     return gpe_step_update(e);
 }
 

@@ -106,6 +106,9 @@ def _advanced_init(layers, mode, kind, spec=None) -> np.ndarray:
         if kind == "xavier_normal":
             torch.nn.init.xavier_normal_(W, gain=1.0 / (1.0 + 0.2 * mode))
             bias = 0.001 if mode > 3 else 0.01
+        elif kind == "xavier_normal_vbeta":                  # refine/vary_potential_parameter_harmonic.py:788-798 (and its two siblings)
+            torch.nn.init.xavier_normal_(W, gain=(0.1 if mode >= 3 else 1.0) / (1.0 + 0.2 * mode))
+            bias = 0.0001 if mode >= 3 else 0.01
         else:
             torch.nn.init.xavier_uniform_(W, gain=1.0 / (1.0 + 0.1 * mode))
             bias = 0.01
@@ -262,16 +265,20 @@ class _PINNBase:
         den = float((nn_out * nn_out).sum())
         return float((predictions.detach() * nn_out).sum()) / den if den > 0 else 1.0
 
-    def _pde_eval(self, inputs, predictions, gamma, p, potential_type, precomputed_potential):
+    def _pde_eval(self, inputs, predictions, gamma, p, potential_type, precomputed_potential, **over):
         if precomputed_potential is None and potential_type not in _POT:
             raise ValueError(f"Unknown potential type: {potential_type}")
         pot = capi.POT_PRECOMPUTED if precomputed_potential is not None else _POT[potential_type]
         s = self._scale_of(inputs, predictions)
-        eng = self._get_engine(potential=pot, p=int(p), w_bc=0.0)
+        eng = self._get_engine(potential=pot, p=int(p), w_bc=0.0, **over)
         eng.set_gamma(float(gamma))
         eng.set_perturb_scale(s)
         eng.bind_points(inputs, precomputed_potential)
+        self._before_residual(eng, inputs)
         return eng.residual()
+
+    def _before_residual(self, eng, inputs):
+        pass
 
     def boundary_loss(self, boundary_points, boundary_values):
         eng = self._get_engine()
@@ -418,11 +425,133 @@ class _GravityWellPINN(_RefinePINN):
             raise ValueError(f"Unknown potential type: {potential_type}")
         return x.clone()
 
+    def _before_residual(self, eng, inputs):               # per-call surface: the Airy base on the points just bound
+        eng.bind_base(*self.base_arrays(_as_np(inputs)[:, 0], self.mode))
+
+    def pde_loss(self, inputs, predictions, gamma, p, potential_type="gravity_well", precomputed_potential=None):
+        if precomputed_potential is None:
+            precomputed_potential = self.compute_potential(inputs, potential_type).reshape(-1).contiguous()      # V = x, as an array
+        return super().pde_loss(inputs, predictions, gamma, p, "gravity_well", precomputed_potential)
+
     def _bind_training_data(self, eng, X_np, X_dev, bpts):
         eng.bind_points(X_dev, V=X_dev[:, 0].contiguous())
         eng.bind_base(*self.base_arrays(X_np[:, 0], self.mode))
         base_b = self.airy_solution(bpts, self.mode).reshape(-1, 1)
         eng.bind_boundary(bpts, -base_b)               # e = base(x_b) + NN(x_b) - 0
+
+
+# ---- beta-sweep flavours: refine/vary_potential_parameter_{harmonic,gravity_well,box_and_gaussian}.py --------------------------
+# Same residual and epoch body as the refine family; what changes is the constructor (beta instead of gamma), that the potential
+# term carries beta, the signature pde_loss(inputs, predictions, gamma, beta, p, ...) and the driver's loop: ONE interaction strength,
+# continuation in beta.
+class _VaryBetaMixin:
+    def _init_beta(self, beta, use_residual):
+        self.beta = beta
+        self.use_residual = use_residual
+        self.gamma = 0.0                                   # set by the driver (train_gpe_model(gamma, beta_values, ...))
+
+    def _beta_potential(self, X_np, potential_type):       # beta * V on the training grid, or None when the engine forms it
+        return None
+
+    def _pde_over(self, beta):                             # engine overrides that carry beta when the engine forms the potential
+        return {}
+
+
+class _VaryHarmonicPINN(_VaryBetaMixin, _RefinePINN):
+    """refine/vary_potential_parameter_harmonic.py:52-342: box [0, L] with the trap V = beta/2 omega^2 (x - center)^2 inside
+    (omega = 10, center = 2.5: :236-238); sine base sqrt(2/L) sin((n+1) pi x / L) (:99-117); forward = network(x)."""
+    OMEGA, CENTER = 10.0, 2.5
+
+    def __init__(self, layers, hbar=1.0, m=1.0, mode=0, beta=1.0, L=5.0, use_residual=True, use_perturbation=True):
+        _RefinePINN.__init__(self, layers, hbar, m, mode, 0.0, use_perturbation)
+        self._init_beta(beta, use_residual)
+        self.L = L
+
+    def _extra_config(self):
+        return dict(base_kind=capi.BASE_BOX, box_L=float(self.L), potential=capi.POT_HARMONIC, pot_scale=0.5 * float(self.beta),
+                    omega=(self.OMEGA, 1.0, 1.0), pot_a=self.CENTER)
+
+    def _pde_over(self, beta):
+        return dict(pot_scale=0.5 * float(beta))
+
+    def box_eigenfunction(self, x, n):
+        return math.sqrt(2.0 / self.L) * torch.sin((n + 1) * math.pi * x / self.L)
+
+    def weighted_hermite_np(self, x, n):                   # target of the pre-training fit of this script: the box eigenfunction (:807)
+        return (math.sqrt(2.0 / self.L) * np.sin((n + 1) * math.pi * np.asarray(x, np.float64) / self.L)).astype(np.float32)
+
+    def get_complete_solution(self, x, perturbation, mode=None):
+        return self.box_eigenfunction(x, self.mode if mode is None else mode) + perturbation
+
+    def compute_potential(self, x, beta, potential_type="harmonic", **kwargs):
+        if potential_type != "harmonic":
+            raise ValueError(f"Unknown potential type: {potential_type}")
+        return beta * 0.5 * kwargs.get("omega", self.OMEGA) ** 2 * (x - kwargs.get("center", self.CENTER)) ** 2
+
+    def pde_loss(self, inputs, predictions, gamma, beta, p, potential_type="harmonic", precomputed_potential=None):
+        if precomputed_potential is None and potential_type != "harmonic":
+            raise ValueError(f"Unknown potential type: {potential_type}")
+        sc, _, _ = self._pde_eval(inputs, predictions, gamma, p, "harmonic", precomputed_potential, **self._pde_over(beta))
+        dev = _device()
+        return (torch.tensor(sc["pde"], dtype=torch.float32, device=dev), torch.tensor(sc["mu"], dtype=torch.float32, device=dev))
+
+
+class _VaryGravityPINN(_VaryBetaMixin, _GravityWellPINN):
+    """refine/vary_potential_parameter_gravity_well.py:52-257: the gravity well with the potential term beta * x * u (:221)."""
+
+    def __init__(self, layers, hbar=1.0, m=1.0, mode=0, beta=1.0, use_residual=True, use_perturbation=True):
+        _GravityWellPINN.__init__(self, layers, hbar, m, mode, 0.0, use_perturbation)
+        self._init_beta(beta, use_residual)
+
+    def _beta_potential(self, X_np, potential_type):
+        return (float(self.beta) * np.asarray(X_np, np.float64)[:, 0]).astype(np.float32)
+
+    def _bind_training_data(self, eng, X_np, X_dev, bpts):
+        super()._bind_training_data(eng, X_np, X_dev, bpts)
+        eng.bind_points(X_dev, V=torch.as_tensor(self._beta_potential(X_np, "gravity_well"), device=X_dev.device))
+
+    def pde_loss(self, inputs, predictions, gamma, beta, p, potential_type="gravity_well", precomputed_potential=None):
+        V = precomputed_potential if precomputed_potential is not None else self.compute_potential(inputs, potential_type)
+        sc, _, _ = self._pde_eval(inputs, predictions, gamma, p, "gravity_well", (float(beta) * V).reshape(-1).contiguous())
+        dev = _device()
+        return (torch.tensor(sc["pde"], dtype=torch.float32, device=dev), torch.tensor(sc["mu"], dtype=torch.float32, device=dev))
+
+
+class _VaryBoxGaussianPINN(_VaryBetaMixin, _BoxPINN):
+    """refine/vary_potential_parameter_box_and_gaussian.py:52-225: box [0, L], forward = network(x) sin(pi x) (:119-130), sine base, the
+    potential term beta * V * u with V = exp(-x^2 / 2) ("gaussian", :147) or 0 ("box")."""
+
+    def __init__(self, layers, hbar=1.0, m=1.0, mode=0, beta=1.0, L=1.0, use_residual=True, use_perturbation=True):
+        _BoxPINN.__init__(self, layers, hbar, m, mode, 0.0, L, use_residual, use_perturbation)
+        self._init_beta(beta, use_residual)
+
+    def _extra_config(self):
+        return dict(base_kind=capi.BASE_BOX, box_L=float(self.L), envelope=capi.ENV_SIN, env_L=1.0, potential=capi.POT_PRECOMPUTED)
+
+    def compute_potential(self, x, potential_type="gaussian", **kwargs):
+        if potential_type == "box":
+            return torch.zeros_like(x)
+        if potential_type == "gaussian":
+            return torch.exp((-x ** 2) / 2)
+        raise ValueError(f"Unknown potential type: {potential_type}")
+
+    def _beta_potential(self, X_np, potential_type):
+        x = np.asarray(X_np, np.float64)[:, 0]
+        if potential_type == "box":
+            return np.zeros_like(x, dtype=np.float32)
+        if potential_type != "gaussian":
+            raise ValueError(f"Unknown potential type: {potential_type}")
+        return (float(self.beta) * np.exp(-x * x / 2)).astype(np.float32)
+
+    def _bind_training_data(self, eng, X_np, X_dev, bpts):
+        eng.bind_points(X_dev, V=torch.as_tensor(self._beta_potential(X_np, self._pot_name), device=X_dev.device))
+        eng.bind_boundary(bpts)
+
+    def pde_loss(self, inputs, predictions, gamma, beta, p, potential_type="gaussian", precomputed_potential=None):
+        V = precomputed_potential if precomputed_potential is not None else self.compute_potential(inputs, potential_type)
+        sc, _, _ = self._pde_eval(inputs, predictions, gamma, p, "box", (float(beta) * V).reshape(-1).contiguous())
+        dev = _device()
+        return (torch.tensor(sc["pde"], dtype=torch.float32, device=dev), torch.tensor(sc["mu"], dtype=torch.float32, device=dev))
 
 
 class _NotebookPINN(_PINNBase):
@@ -517,7 +646,7 @@ def _refine_pretrain(model, mode, X_train, epochs=5000, lr=1e-3, verbose=False):
 
 def _refine_train(gamma_values, modes, p, X_train, lb, ub, layers, epochs, tol, perturb_const,
                   potential_type="harmonic", lr=1e-5, verbose=True, pretrain="reference", chunk=500, _cls=None, _descending=False,
-                  **model_kw):
+                  _make_model=None, _init_fn=None, _pot_over=None, _label="γ", **model_kw):
     """train_gpe_model of refine/harmonic_pinn_simulation.py:220-430 (PL-PINN, gamma continuation).
 
     Differences from the reference, all deliberate:
@@ -530,8 +659,12 @@ def _refine_train(gamma_values, modes, p, X_train, lb, ub, layers, epochs, tol, 
     Epoch bodies are enqueued `chunk` at a time with no host synchronisation; early stopping (:389-400) is evaluated on the
     device after every update, so the stop epoch is exact.
     """
-    if potential_type not in _POT:
+    if _pot_over is None and potential_type not in _POT:
         raise ValueError(f"Unknown potential type: {potential_type}")
+    # (the beta-sweep drivers below reuse this loop: `gamma_values` is then the list of beta values, _make_model builds the model of a
+    # stage, _pot_over replaces the potential override of the engine configuration, _init_fn the cold-start initialiser)
+    pot_over = {"potential": _POT[potential_type]} if _pot_over is None else dict(_pot_over)
+    init_fn = _init_fn or _refine_advanced_initialization
     X = _as_np(X_train).astype(np.float64)
     dx = X[1, 0] - X[0, 0]
     dev = _device()
@@ -549,8 +682,8 @@ def _refine_train(gamma_values, modes, p, X_train, lb, ub, layers, epochs, tol, 
         normal_const = None
         for gamma in gamma_values:
             if verbose:
-                print(f"\nTraining for γ = {gamma:.2f}, mode = {mode}, nonlinearity p = {p}")
-            model = (_cls or _RefinePINN)(layers, mode=mode, gamma=gamma, **model_kw)
+                print(f"\nTraining for {_label} = {gamma:.2f}, mode = {mode}, nonlinearity p = {p}")
+            model = _make_model(mode, gamma) if _make_model else (_cls or _RefinePINN)(layers, mode=mode, gamma=gamma, **model_kw)
             if prev_model is not None:
                 model.load_state_dict(prev_model.state_dict())
             elif gamma == 0.0 and pretrain is not None:
@@ -559,13 +692,13 @@ def _refine_train(gamma_values, modes, p, X_train, lb, ub, layers, epochs, tol, 
                 else:
                     model = pretrain(model, mode, X_train)
             else:
-                model.apply(lambda m: _refine_advanced_initialization(m, mode))
+                model.apply(lambda m: init_fn(m, mode))
             if normal_const is None:                                   # :333-335
                 nn0 = model.forward(X_dev)
                 normal_const = float(nn0.max())
                 constant_history[mode] = torch.tensor(normal_const)
             model.perturb_scale = perturb_const / normal_const
-            eng = model._get_engine(potential=_POT[potential_type], p=int(p), dx=float(dx), lr=float(lr),
+            eng = model._get_engine(**pot_over, p=int(p), dx=float(dx), lr=float(lr),
                                     sched=capi.SCHED_COSINE_LOSS, T_0=200.0, T_mult=2.0, eta_min=1e-6,
                                     w_bc=10.0, w_norm=20.0, stop_tol=float(tol), stop_patience=2000,
                                     history_capacity=max(int(epochs), 1))
@@ -725,6 +858,46 @@ def _b2g_train(gamma_values, modes, p, X_train, lb, ub, layers, epochs, tol, per
                          _cls=_BoxToGaussianPINN, L=float(ub), **kw)
 
 
+def _vbeta_advanced_initialization(m, mode):
+    """advanced_initialization of the beta-sweep scripts (refine/vary_potential_parameter_harmonic.py:788-798): from mode 3 on a ten
+    times smaller gain and bias 1e-4."""
+    m._flat = _advanced_init(m.layers, mode, "xavier_normal_vbeta", m._spec())
+    if m._engine is not None:
+        m._engine.set_params(m._flat)
+
+
+def _vbeta_train(cls, valid_potentials, with_L):
+    """train_gpe_model(gamma, beta_values, modes, p, X_train, lb, ub, layers, epochs, tol, perturb_const, potential_type, lr, verbose)
+    of refine/vary_potential_parameter_harmonic.py:344-556 (gravity well :259-470, box + Gaussian :227-439): the refine family's epoch
+    body and early stopping, ONE interaction strength gamma, warm-started continuation in beta (sorted ascending), pre-training on the
+    analytic base when the first beta is 0.0 (:427-430), normal_const taken at the first epoch of the first beta (the scripts define it
+    only when that beta is 0 -- 1 in the gravity-well script, :374 there -- and raise NameError otherwise: quirk Q6)."""
+    def train(gamma, beta_values, modes, p, X_train, lb, ub, layers, epochs, tol, perturb_const, potential_type="box", lr=1e-5,
+              verbose=True, **kw):
+        if potential_type not in valid_potentials:         # the scripts raise this from compute_potential in the first epoch body
+            raise ValueError(f"Unknown potential type: {potential_type}")
+
+        def make(mode, beta):
+            mdl = cls(layers, mode=mode, beta=beta, L=ub) if with_L else cls(layers, mode=mode, beta=beta)
+            mdl.gamma = float(gamma)
+            mdl._pot_name = potential_type
+            return mdl
+
+        return _refine_train(beta_values, modes, p, X_train, lb, ub, layers, epochs, tol, perturb_const, potential_type, lr, verbose,
+                             _make_model=make, _init_fn=_vbeta_advanced_initialization, _pot_over={}, _label="β", **kw)
+    return train
+
+
+vary_beta_harmonic = types.SimpleNamespace(GrossPitaevskiiPINN=_VaryHarmonicPINN, train_gpe_model=_vbeta_train(_VaryHarmonicPINN, ("harmonic",), True),
+                                           advanced_initialization=_vbeta_advanced_initialization,
+                                           pretrain_on_analytical_solution=_refine_pretrain, normalized_wavefunction=_refine_wavefunction)
+vary_beta_gravity_well = types.SimpleNamespace(GrossPitaevskiiPINN=_VaryGravityPINN, train_gpe_model=_vbeta_train(_VaryGravityPINN, ("gravity_well",), False),
+                                               advanced_initialization=_vbeta_advanced_initialization,
+                                               pretrain_on_analytical_solution=_refine_pretrain)
+vary_beta_box_and_gaussian = types.SimpleNamespace(GrossPitaevskiiPINN=_VaryBoxGaussianPINN,
+                                                   train_gpe_model=_vbeta_train(_VaryBoxGaussianPINN, ("box", "gaussian"), True),
+                                                   advanced_initialization=_vbeta_advanced_initialization,
+                                                   pretrain_on_analytical_solution=_refine_pretrain)
 box_to_gaussian = types.SimpleNamespace(GrossPitaevskiiPINN=_BoxToGaussianPINN, train_gpe_model=_b2g_train,
                                         advanced_initialization=_refine_advanced_initialization)
 gravity_well = types.SimpleNamespace(GrossPitaevskiiPINN=_GravityWellPINN, train_gpe_model=_gravity_train,

@@ -92,3 +92,34 @@ def problem_from_box2gauss(fx) -> go.Problem:
                       potential=go.POT_GAUSSIAN, pot_a=0.5, gamma=float(fx["gamma"]), p=int(fx["p"]), base_mode=int(fx["mode"]),
                       base_kind=go.BASE_BOX, box_L=float(fx["ub"]), perturb_scale=float(fx["perturb_const"]) / float(fx["normal_const"]),
                       bc_nn_scale=1.0, w_bc=10.0, w_norm=20.0, dx=float(fx["dx"]))
+
+
+VBETA_SEEDS = {"fx_vbeta_harmonic_m0_b0.4_g0.npz": 0, "fx_vbeta_harmonic_m3_b1_g2_p4.npz": 2, "fx_vbeta_gravity_m0_b0.5_g0.npz": 0,
+               "fx_vbeta_gravity_m1_b2_g5.npz": 1, "fx_vbeta_boxgauss_m0_b10_g0.npz": 0, "fx_vbeta_boxgauss_m1_b3_g5_p2.npz": 1}
+
+
+def vbeta_names():
+    return sorted(VBETA_SEEDS)
+
+
+def problem_from_vbeta(fx):
+    """The beta-sweep flavours (refine/vary_potential_parameter_{harmonic,gravity_well,box_and_gaussian}.py; tests/golden/
+    make_golden_vary_beta.py) -> (Problem, dict of the arrays the oracle / engine are handed: V_pre, base_pre, bc_target).
+    harmonic : box [0, L], sine base, V = beta/2 omega^2 (x - 2.5)^2 with omega = 10, formed analytically (pot_scale = beta/2, pot_a)
+    gravity  : Airy base as arrays, potential term beta * x * u -> precomputed potential beta x
+    boxgauss : forward = NN sin(pi x), sine base, potential term beta exp(-x^2/2) u -> precomputed potential"""
+    flavour = str(fx["flavour"])
+    beta = float(fx["beta"])
+    x = fx["x"].astype(np.float64)
+    common = dict(layers=[int(v) for v in fx["layers"]], activation=1, kinetic_coeff=1.0, gamma=float(fx["gamma"]), p=int(fx["p"]),
+                  base_mode=int(fx["mode"]), perturb_scale=float(fx["perturb_const"]) / float(fx["normal_const"]), bc_nn_scale=1.0,
+                  w_bc=10.0, w_norm=20.0, dx=float(fx["dx"]))
+    if flavour == "harmonic":
+        return go.Problem(potential=go.POT_HARMONIC, pot_scale=0.5 * beta, omega=(10.0, 1.0, 1.0), pot_a=2.5, base_kind=go.BASE_BOX,
+                          box_L=float(fx["ub"]), **common), {}
+    if flavour == "gravity":
+        return (go.Problem(potential=go.POT_PRECOMPUTED, base_kind=go.BASE_PRECOMPUTED, **common),
+                dict(V_pre=beta * x[:, 0], base_pre=(fx["base"][:, 0], fx["base_x"][:, 0], fx["base_xx"][:, 0]),
+                     bc_target=-fx["base_boundary"]))
+    return (go.Problem(potential=go.POT_PRECOMPUTED, base_kind=go.BASE_BOX, box_L=float(fx["ub"]), envelope=go.ENV_SIN, env_L=1.0,
+                       **common), dict(V_pre=beta * np.exp(-x[:, 0] ** 2 / 2)))

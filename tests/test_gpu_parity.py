@@ -1057,3 +1057,29 @@ def test_split_bf16_kernels_match_oracle(name, mode):
     finally:
         for k, v in old.items():
             os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+
+
+@pytest.mark.parametrize("name", H.vbeta_names())
+def test_golden_vary_beta_oplevel(name):
+    """Row f3, beta-sweep flavours (refine/vary_potential_parameter_{harmonic,gravity_well,box_and_gaussian}.py): both kernel sets against
+    the tensors of the reference's own classes -- u, lambda, total loss, gradient of the epoch-0 body."""
+    fx = H.load_fx(name)
+    pb, arr = H.problem_from_vbeta(fx)
+    x = fx["x"]
+    xb = np.array([[float(fx["lb"])], [float(fx["ub"])]], np.float32)
+    for path in ("generic", "fused"):
+        eng = Engine(cfg_from_problem(pb, path=PATHS[path]))
+        eng.set_params(fx["flat0"])
+        V = arr.get("V_pre")
+        eng.bind_points(torch.as_tensor(x, device="cuda"), V=None if V is None else torch.as_tensor(V.astype(np.float32), device="cuda"))
+        if "base_pre" in arr:
+            eng.bind_base(*arr["base_pre"])
+        tgt = arr.get("bc_target")
+        eng.bind_boundary(torch.as_tensor(xb, device="cuda"), None if tgt is None else torch.as_tensor(tgt.astype(np.float32), device="cuda"))
+        rs, psi, res = eng.residual()
+        assert H.rel_err(psi.cpu().numpy(), fx["u"]) < 2e-6
+        assert abs(rs["mu"] - float(fx["lam"])) < 5e-5 * abs(float(fx["lam"]))
+        sc = eng.step()
+        assert abs(sc["loss"] - float(fx["total"])) < 1e-3 * float(fx["total"])
+        assert H.rel_err(eng.get_grad(), fx["grad0"]) < 1e-3
+        eng.close()

@@ -393,3 +393,76 @@ def test_box_to_gaussian_driver_known_answer():
     assert list(sd.keys())[2] == "network.2.lin1.weight" and sd["network.3.lin2.weight"].shape == (64, 64)
     with pytest.raises(ValueError):
         b2g.train_gpe_model([0.0], [0], 3, X, 0.0, 1.0, [1, 64, 64, 64, 1], 5, 1e-5, 0.01, potential_type="harmonic")
+
+
+# ---- beta-sweep flavours of the refine family (refine/vary_potential_parameter_*.py; tests/golden/make_golden_vary_beta.py) ----------
+_VBETA_NS = {"harmonic": gpe_pinn.vary_beta_harmonic, "gravity": gpe_pinn.vary_beta_gravity_well, "boxgauss": gpe_pinn.vary_beta_box_and_gaussian}
+_VBETA_POT = {"harmonic": "harmonic", "gravity": "gravity_well", "boxgauss": "gaussian"}
+
+
+@pytest.mark.parametrize("name", H.vbeta_names())
+def test_vary_beta_class_surface_against_golden(name):
+    """The drop-in class of each beta-sweep script, called the way its train_gpe_model calls it: forward, get_complete_solution,
+    compute_potential(x, beta, ...) / compute_potential(x, ...), pde_loss(inputs, predictions, gamma, beta, p, potential_type),
+    boundary_loss, normalization_loss -- against the numbers of the reference's own class from the same seed."""
+    fx = H.load_fx(name)
+    flavour, mode, beta = str(fx["flavour"]), int(fx["mode"]), float(fx["beta"])
+    ns = _VBETA_NS[flavour]
+    layers = [int(v) for v in fx["layers"]]
+    torch.manual_seed(H.VBETA_SEEDS[name])
+    kw = dict(L=float(fx["ub"])) if flavour != "gravity" else {}
+    model = ns.GrossPitaevskiiPINN(layers, mode=mode, beta=beta, **kw)
+    model.apply(lambda m_: ns.advanced_initialization(m_, mode))
+    X = torch.as_tensor(fx["x"], device="cuda")
+    u_nn = model.forward(X)
+    assert H.rel_err(u_nn.cpu().numpy(), fx["forward_out"]) < 2e-6
+    nc = float(u_nn.max())
+    assert abs(nc - float(fx["normal_const"])) < 2e-6 * abs(nc)
+    u_pred = float(fx["perturb_const"]) * (u_nn / nc)
+    u = model.get_complete_solution(X, u_pred)
+    assert H.rel_err(u.cpu().numpy(), fx["u"]) < 3e-6
+    pot = _VBETA_POT[flavour]
+    V = model.compute_potential(X, beta, pot) if flavour == "harmonic" else model.compute_potential(X, pot)
+    assert H.rel_err(V.cpu().numpy(), fx["V"]) < 2e-6
+    pde, lam = model.pde_loss(X, u_pred, float(fx["gamma"]), beta, int(fx["p"]), pot)
+    assert abs(float(lam) - float(fx["lam"])) < 5e-5 * abs(float(fx["lam"]))
+    assert abs(float(pde) - float(fx["pde_loss"])) < 1e-3 * max(float(fx["pde_loss"]), 1e-4)
+    bl = model.boundary_loss(torch.tensor([[float(fx["lb"])], [float(fx["ub"])]], device="cuda"), torch.zeros((2, 1), device="cuda"))
+    assert abs(float(bl) - float(fx["bc_loss"])) < 1e-4 * max(float(fx["bc_loss"]), 1e-8) + 1e-10
+    nl = model.normalization_loss(u, float(fx["dx"]))
+    assert abs(float(nl) - float(fx["norm_loss"])) < 1e-3 * max(float(fx["norm_loss"]), 1e-6)
+    with pytest.raises(ValueError, match="Unknown potential type"):
+        model.pde_loss(X, u_pred, 0.0, beta, 3, "no_such_potential")
+    model.close()
+
+
+@pytest.mark.parametrize("flavour", ["harmonic", "gravity", "boxgauss"])
+def test_vary_beta_driver_against_reference_run(flavour):
+    """train_gpe_model(gamma, beta_values, ...) of the three beta-sweep scripts against one seeded run of the reference's own function:
+    the five return values -- lambda_table rows (beta, lambda), normal_const, stop epochs, history cadence, state_dict layout.  lambda
+    of a 400-epoch stage with q = 0.01 is set by the base function to first order; the trajectory-dependent part is bounded below."""
+    fx = H.load_fx(f"fx_vbetadriver_{flavour}.npz")
+    ns = _VBETA_NS[flavour]
+    layers = [int(v) for v in fx["layers"]]
+    N, epochs, mode = int(fx["N"]), int(fx["epochs"]), int(fx["mode"])
+    betas = [float(b) for b in fx["betas"]]
+    lb, ub = float(fx["lb"]), float(fx["ub"])
+    torch.manual_seed(int(fx["seed"]))
+    X = np.linspace(lb, ub, N).reshape(-1, 1)
+    models, lam_table, hist, const, ep = ns.train_gpe_model(float(fx["gamma"]), betas, [mode], int(fx["p"]), X, lb, ub, layers, epochs,
+                                                           float(fx["tol"]), float(fx["perturb_const"]),
+                                                           potential_type=_VBETA_POT[flavour], lr=float(fx["lr"]), verbose=False)
+    got, ref = np.array(lam_table[mode], dtype=np.float64), fx["lam_table"]
+    np.testing.assert_array_equal(got[:, 0], ref[:, 0])
+    np.testing.assert_allclose(got[:, 1], ref[:, 1], atol=2e-3, rtol=5e-4)
+    assert abs(float(const[mode]) - float(fx["const"])) <= 0.05 * abs(float(fx["const"]))
+    for b, e_ref in zip(betas, fx["stop_epochs"]):
+        assert ep[mode][b] == int(e_ref) == epochs                       # no stage reaches tol = 1e-5 in 400 epochs, here or there
+        h = hist[mode][b]
+        assert len(h["loss"]) == len(fx[f"loss_b{b}"]) == (epochs + 9) // 10
+        assert len(h["lambda"]) == len(fx[f"lambda_b{b}"]) == (epochs + 99) // 100 == len(h["constraint"])
+        sd = models[mode][b].state_dict()
+        assert [tuple(v.shape) for v in sd.values()] == [s for k in range(len(layers) - 1) for s in ((layers[k + 1], layers[k]), (layers[k + 1],))]
+    # the first recorded loss of the first stage is fixed by the ansatz and the (pre-trained or initialised) network
+    b0 = betas[0]
+    assert abs(hist[mode][b0]["loss"][0] - fx[f"loss_b{b0}"][0]) <= 0.3 * abs(fx[f"loss_b{b0}"][0]) + 1e-6

@@ -303,3 +303,43 @@ def test_box_to_gaussian_residual_network_oplevel(name):
     assert abs(sc["pde"] - float(fx["pde_loss"])) < 1e-3 * float(fx["pde_loss"])
     assert abs(sc["loss"] - float(fx["total"])) < 1e-3 * float(fx["total"])
     assert H.rel_err(grad, fx["grad0"]) < 1e-3
+
+
+# ---- row f3, beta-sweep flavours: refine/vary_potential_parameter_{harmonic,gravity_well,box_and_gaussian}.py -----------------------
+@pytest.mark.parametrize("name", H.vbeta_names())
+def test_vary_beta_oplevel(name):
+    """GrossPitaevskiiPINN(layers, ..., beta[, L]).pde_loss(inputs, predictions, gamma, beta, p, ...) and the epoch-0 body of
+    train_gpe_model(gamma, beta_values, ...) of the three scripts (fixtures from the imported classes) vs the oracle."""
+    fx = H.load_fx(name)
+    pb, arr = H.problem_from_vbeta(fx)
+    x = fx["x"].astype(np.float64)
+    xb = np.array([[float(fx["lb"])], [float(fx["ub"])]])
+    sc, grad, res = go.full_loss_and_grad(pb, fx["flat0"].astype(np.float64), x, xb, bc_target=arr.get("bc_target"),
+                                          V_pre=arr.get("V_pre"), base_pre=arr.get("base_pre"))
+    assert H.rel_err(res["psi"], fx["u"]) < 2e-6
+    if str(fx["flavour"]) == "harmonic":                      # the potential the class returns for this beta
+        assert H.rel_err(go.potential(pb, x), fx["V"][:, 0]) < 1e-6
+    assert abs(sc["mu"] - float(fx["lam"])) < 5e-5 * abs(float(fx["lam"]))
+    assert abs(sc["pde"] - float(fx["pde_loss"])) < 1e-3 * max(float(fx["pde_loss"]), 1e-4)
+    assert abs(sc["bc"] - float(fx["bc_loss"])) < 1e-4 * max(float(fx["bc_loss"]), 1e-8)
+    assert abs(sc["loss"] - float(fx["total"])) < 1e-3 * max(float(fx["total"]), 1e-4)
+    assert H.rel_err(grad, fx["grad0"]) < 1e-3
+
+
+def test_vary_beta_seeded_construction_bit_exact():
+    """torch.manual_seed(seed); GrossPitaevskiiPINN(layers, mode=, beta=[, L=]); model.apply(advanced_initialization) of the three
+    beta-sweep scripts (their initialiser: ten times smaller gain and bias 1e-4 from mode 3 on, :788-798) -- bit for bit."""
+    import torch
+    import gpe_pinn
+    ns = {"harmonic": gpe_pinn.vary_beta_harmonic, "gravity": gpe_pinn.vary_beta_gravity_well, "boxgauss": gpe_pinn.vary_beta_box_and_gaussian}
+    for name, seed in H.VBETA_SEEDS.items():
+        fx = H.load_fx(name)
+        flavour, mode = str(fx["flavour"]), int(fx["mode"])
+        layers = [int(v) for v in fx["layers"]]
+        torch.manual_seed(seed)
+        kw = dict(L=float(fx["ub"])) if flavour != "gravity" else {}
+        model = ns[flavour].GrossPitaevskiiPINN(layers, mode=mode, beta=float(fx["beta"]), **kw)
+        model.apply(lambda m_: ns[flavour].advanced_initialization(m_, mode))
+        np.testing.assert_array_equal(model._flat, fx["flat0"], err_msg=name)
+    with pytest.raises(ValueError, match="Unknown potential type"):          # the driver's default potential_type='box' is not one of the class's
+        gpe_pinn.vary_beta.train_gpe_model(0, [0.0], [0], 3, None, 0, 5, [1, 8, 8, 1], 10, 1e-5, 0.01)
