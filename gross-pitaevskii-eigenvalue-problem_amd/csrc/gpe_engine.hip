@@ -104,7 +104,15 @@ GPE_DEV void adam_element(float graw, float& m, float& v, float& th, float coef,
     th = th - ss * (m / denom);                    // param.addcdiv_(exp_avg, denom, value=-step_size)
 }
 
-template <bool MULTI>
+// gradient element as the update reads it.  SC1 (the update runs inside the slab-reduction launch, k_reduce_update below): the values
+// were stored by OTHER workgroups of this launch with write-through (sc1) stores -- read them past this CU's L1
+template <bool SC1>
+GPE_DEV float grad_load(const float* p) {
+    if constexpr (SC1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+
+template <bool MULTI, bool SC1 = false>
 GPE_DEV void update_core(int P, float* __restrict__ theta, float* __restrict__ am,
                          float* __restrict__ av, const float* __restrict__ grad,
                          const double* __restrict__ sums_in, const double* __restrict__ lsums_in,
@@ -140,14 +148,14 @@ GPE_DEV void update_core(int P, float* __restrict__ theta, float* __restrict__ a
     long long p_step = 0;
     int p_stopped = 0;
     if (threadIdx.x == 0) {
-        p_num = sums[S_NUM]; p_den = sums[S_DEN]; p_bcse = lsums[LS_BC_SE2]; p_sr2 = grad[P + GT_SUM_R2];
+        p_num = sums[S_NUM]; p_den = sums[S_DEN]; p_bcse = lsums[LS_BC_SE2]; p_sr2 = grad_load<SC1>(&grad[P + GT_SUM_R2]);
         p_lr = odr->lr; p_b1p = odr->b1p; p_b2p = odr->b2p; p_step = odr->step; p_stopped = odr->stopped;
     }
     if constexpr (!MULTI) {
         double acc = 0.0;
         if (cached) {
 #pragma unroll
-            for (int k = 0; k < REG_E; ++k) { const int i = threadIdx.x + k * 1024; cg[k] = i < P ? grad[i] : 0.f; }
+            for (int k = 0; k < REG_E; ++k) { const int i = threadIdx.x + k * 1024; cg[k] = i < P ? grad_load<SC1>(&grad[i]) : 0.f; }
 #pragma unroll
             for (int k = 0; k < REG_E; ++k) {
                 const int i = threadIdx.x + k * 1024;
@@ -156,7 +164,7 @@ GPE_DEV void update_core(int P, float* __restrict__ theta, float* __restrict__ a
 #pragma unroll
             for (int k = 0; k < REG_E; ++k) { const double g = cg[k]; acc += g * g; }          // (same order as the loop below)
         } else
-        for (int i = threadIdx.x; i < P; i += 1024) { double g = grad[i]; acc += g * g; }
+        for (int i = threadIdx.x; i < P; i += 1024) { double g = grad_load<SC1>(&grad[i]); acc += g * g; }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -185,7 +193,7 @@ GPE_DEV void update_core(int P, float* __restrict__ theta, float* __restrict__ a
         }
         double loss = ph.w_pde * pde + ph.w_bc * bc + ph.w_norm * nrm + ph.w_sym * sym + ph.w_orth * orth + ph.w_riesz * riesz;
         if (mse_mode) {           // pre-training: loss = mean((NN - target)^2); plain Adam (no clip, no scheduler, no early stop)
-            loss = (double)grad[P + GT_MSE_SE2] / (ph.n_global * ph.n_out);
+            loss = (double)grad_load<SC1>(&grad[P + GT_MSE_SE2]) / (ph.n_global * ph.n_out);
             lam = 0.0; pde = 0.0; nrm = 0.0; bc = 0.0; sym = 0.0; orth = 0.0; riesz = 0.0;
         }
         int skip = !(isfinite(loss) && isfinite(gn));
@@ -285,7 +293,7 @@ GPE_DEV void update_core(int P, float* __restrict__ theta, float* __restrict__ a
         const float b1 = oc.beta1, b2 = oc.beta2, eps = oc.eps;
         for (int i = lo + threadIdx.x; i < hi; i += 1024) {
             float m = am[i], v = av[i], th = theta[i];
-            adam_element(grad[i], m, v, th, coef, ss, b2s, b1, b2, eps);
+            adam_element(grad_load<SC1>(&grad[i]), m, v, th, coef, ss, b2s, b1, b2, eps);
             theta[i] = th;
             am[i] = m; av[i] = v;
         }
@@ -320,6 +328,56 @@ __global__ void k_tail(float* __restrict__ grad, const float* __restrict__ add, 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (add && i < P) grad[i] += add[i];
     if (i == 0) { grad[P + GT_SUM_R2] = (float)dsc[0]; grad[P + GT_MSE_SE2] = (float)dsc[2]; }
+}
+
+// Slab reduction AND update in one launch (small parameter vectors, whole steps: gpe_step / gpe_run).  At the reference's batch sizes
+// the update was a launch of its own whose ONE workgroup started only when the whole reduction grid had drained: 2.6 us of launch plus a
+// chain of dependent L2 round trips (10.4 of a 40.5 us step at 4 000 points).  Here every workgroup reduces its 64 columns as
+// k_grad_reduce does and stores them write-through (sc1: no L2 write-back fence -- the release fence in every workgroup is what made the
+// round-3 attempt at this fusion slower), takes a ticket, and the workgroup whose ticket is the last runs the single-workgroup update on
+// the spot, reading the gradient past its L1 (hand-off form of MI355X_MICROARCH.md, "Valid forms": sc1 stores, every storing wave's
+// vmcnt(0), workgroup barrier, one agent-scope atomic add per workgroup, the last adder loads sc1 behind a barrier).  Same arithmetic in
+// the same order as k_grad_reduce + k_update<false>: bit-identical results (test_update_kernel_forms_are_bit_identical).
+__global__ __launch_bounds__(1024) void k_reduce_update(const float* __restrict__ gslab, int nslab, int Ppad, int P, float* __restrict__ grad,
+                                                         const float* __restrict__ add, const double* __restrict__ tail_dsc,
+                                                         unsigned* __restrict__ ticket,
+                                                         float* __restrict__ theta, float* __restrict__ am, float* __restrict__ av,
+                                                         const double* __restrict__ sums_in, const double* __restrict__ lsums_in,
+                                                         Phys ph, OptCfg oc, OptDev* __restrict__ od, gpe_scalars* __restrict__ hist, int cap,
+                                                         gpe_scalars* __restrict__ last, double bc_cnt, NetDesc nd, int H,
+                                                         float* __restrict__ Wpk, float* __restrict__ WpkT, int n_pack,
+                                                         double* __restrict__ dbl, int n_dbl, int pack_mode) {
+    __shared__ float red[16][64];
+    __shared__ int s_last;
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (i < P)
+        for (int b = g; b < nslab; b += 16) s += gslab[(size_t)b * Ppad + i];
+    red[g][lane] = s;
+    __syncthreads();
+    if (g == 0 && i < P) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][lane];
+        if (add) t += add[i];
+        __hip_atomic_store(&grad[i], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        __hip_atomic_store(&grad[P + GT_SUM_R2], (float)tail_dsc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&grad[P + GT_MSE_SE2], (float)tail_dsc[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // every storing wave: its stores have left the CU
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = old == gridDim.x - 1;
+        if (s_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // every other workgroup has drawn: ready for the next launch
+    }
+    __syncthreads();
+    if (!s_last) return;
+    update_core<false, true>(P, theta, am, av, grad, sums_in, lsums_in, ph, oc, od, hist, cap, last, bc_cnt, 1, 0, nd, H, Wpk, WpkT, n_pack, dbl,
+                             n_dbl, nullptr, nullptr, pack_mode);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -375,6 +433,10 @@ struct gpe_engine {
     int fh_nslots = 0;             // ... this many triples (= workgroups of that forward launch)
     int64_t fuse_head_tile_min = 32769;   // f_forward (per-wave tiles) runs the head from this many points on (GPE_FUSE_HEAD_TILE_MIN)
     double* head_slots = nullptr;  // [HEAD_SLOTS][4]
+    bool fuse_update = true;       // small P, whole steps: the last-arriving workgroup of the slab reduction runs the update (k_reduce_update; GPE_FUSE_UPDATE=0)
+    bool fu_want = false;          // gpe_step / graph capture in progress: reduction and update are enqueued back to back
+    bool fu_done = false;          // this step's update already ran inside the slab reduction
+    unsigned* upd_ticket = nullptr;
     UpdSnap* upd_snap = nullptr;   // multi-workgroup update (P >= UPD_MULTI_MIN): partial norms + snapshot of sums / optimiser state
     gpe_scalars *hist = nullptr, *last = nullptr;
     int cap = 65536;
@@ -404,6 +466,7 @@ struct gpe_engine {
     bool bc_inflight = false;
     // gpe_run replays one captured step (hipGraph) while every by-value launch argument is unchanged
     bool use_graph = false;
+    int graph_steps = 8;           // steps captured per graph (GPE_GRAPH_STEPS)
     hipStream_t cap_stream = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     std::vector<char> graph_key;
@@ -1014,6 +1077,14 @@ static int mlp_backward(gpe_engine* e, Batch& b, bool close = false, bool assign
             if (e->bc_inflight) add = e->grad_bc;
             e->bc_inflight = false;
         }
+        if (close && assign && e->fu_want && e->fuse_update && e->upd_ticket && !e->upd_snap && e->update_cache && e->P <= 13 * 1024 && !e->comm) {
+            const int n_pack = (e->nd.n_lin - 2) * e->H * e->H;
+            hipLaunchKernelGGL(k_reduce_update, dim3(cdiv(e->P, 64)), dim3(1024), 0, e->stream, e->gslab, nred, e->Ppad, e->P, e->grad, add,
+                               (const double*)e->dsc(), e->upd_ticket, e->theta, e->am, e->av, (const double*)e->sums(), (const double*)e->lsums(),
+                               e->ph, e->oc, e->od, e->hist, e->cap, e->last, bc_count(e), e->nd, e->H, e->Wpk, e->WpkT, n_pack, e->dbl,
+                               (int)(S_COUNT + LS_COUNT + 4), ((e->fwd_b6 || e->bwd_b6 || e->H > 64) ? 1 : 2));
+            e->fu_done = true;
+        } else
         hipLaunchKernelGGL(k_grad_reduce, dim3(cdiv(e->P, 64)), dim3(1024), 0, e->stream, e->gslab, nred, e->Ppad,
                            e->P, e->grad, add, close ? (const double*)e->dsc() : (const double*)nullptr, assign ? 1 : 0);
     } else {
@@ -1343,6 +1414,9 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
         const char* envf6 = getenv("GPE_FUSE_HEAD_MAX");
         if (envf6) e->fuse_head_max = atoll(envf6);
         if (ok && e->fuse_head) ok = alloc((void**)&e->head_slots, (size_t)HEAD_SLOTS * 4 * sizeof(double));
+        const char* envfu = getenv("GPE_FUSE_UPDATE");
+        e->fuse_update = !(envfu && atoi(envfu) == 0);
+        if (ok && e->fuse_update) ok = alloc((void**)&e->upd_ticket, 64);
 
     }
     if (ok && e->path == GPE_PATH_FUSED) {
@@ -1446,6 +1520,8 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
         e->merge_bc = !envb || atoi(envb) != 0;
         const char* envg = getenv("GPE_GRAPH");
         e->use_graph = envg && atoi(envg) != 0;    // opt-in: measured 6 % slower than plain launches on ROCm 7.2 (141 vs 133 us/step)
+        const char* envgs = getenv("GPE_GRAPH_STEPS");
+        if (envgs && atoi(envgs) >= 1 && atoi(envgs) <= 64) e->graph_steps = atoi(envgs);
         const char* envq = getenv("GPE_SIDE_STREAM");
         if (ok && (!envq || atoi(envq) != 0)) {
             if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
@@ -1480,7 +1556,7 @@ void gpe_destroy(gpe_engine* e) {
     free_batch(e->main); free_batch(e->bc); free_batch(e->sym); free_batch(e->aux); free_batch(e->mse);
     for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
     if (e->ext_exchange) { e->grad = nullptr; e->dbl = nullptr; }
-    void* ps[] = {e->theta, e->am, e->av, e->grad, e->dbl, e->od, e->hist, e->last, (void*)e->orth_dev, e->Wpk, e->WpkT, e->gslab, e->gslab_bc, e->grad_bc, (void*)e->upd_snap, (void*)e->head_slots};
+    void* ps[] = {e->theta, e->am, e->av, e->grad, e->dbl, e->od, e->hist, e->last, (void*)e->orth_dev, e->Wpk, e->WpkT, e->gslab, e->gslab_bc, e->grad_bc, (void*)e->upd_snap, (void*)e->head_slots, (void*)e->upd_ticket};
     for (void* p : ps) if (p) (void)hipFree(p);
     delete e;
 }
@@ -1700,7 +1776,7 @@ int gpe_step_begin(gpe_engine* e) {
     if (e->cfg.base_mode >= 0 && e->cfg.base_kind == GPE_BASE_PRECOMPUTED && !e->orth_host[4])
         FAIL(e, GPE_ERR_STATE, "precomputed base requested but gpe_bind_base was not called");
     int rc;
-    e->fh_now = false; e->seedf_now = false;      // per-step flags: a step that failed half-way must not leave them behind
+    e->fh_now = false; e->seedf_now = false; e->fu_done = false;      // per-step flags: a step that failed half-way must not leave them behind
     e->phase = 0;
     if ((rc = launch_begin(e))) return rc;
     if ((rc = bc_fork(e, true))) return rc;
@@ -1815,6 +1891,7 @@ static double bc_count(gpe_engine* e) {
 int gpe_step_update(gpe_engine* e) {
     if (!e) return GPE_ERR_INVALID;
     if (e->phase != 2) FAIL(e, GPE_ERR_STATE, "step_update without step_backward");
+    if (e->fu_done) { e->fu_done = false; after_update(e); e->phase = 0; return GPE_OK; }      // the slab reduction's last workgroup ran it
     launch_update(e, e->grad, e->sums(), e->lsums(), bc_count(e), 1, 0, nullptr);
     HIPCHK(e, hipGetLastError());
     after_update(e);
@@ -2136,7 +2213,10 @@ int gpe_step(gpe_engine* e, gpe_scalars* out) {
     rc = gpe_step_begin(e);
     e->fh_want = false;
     if (rc) return rc;
-    if ((rc = gpe_step_backward(e))) return rc;
+    e->fu_want = true;                            // ... and backward and update: the update may ride in the slab reduction
+    rc = gpe_step_backward(e);
+    e->fu_want = false;
+    if (rc) { e->fu_done = false; return rc; }
     if ((rc = gpe_step_update(e))) return rc;
     if (out) return gpe_read_scalars(e, out);
     return GPE_OK;
@@ -2176,10 +2256,16 @@ static int graph_build(gpe_engine* e) {
     hipGraph_t g = nullptr;
     int rc = GPE_OK;
     if (hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { e->stream = s0; return GPE_ERR_HIP; }
-    e->fh_want = true;
-    rc = gpe_step_begin(e);
-    e->fh_want = false;
-    if (!rc && !(rc = gpe_step_backward(e))) rc = gpe_step_update(e);
+    // graph_steps consecutive steps per graph: ONE hipGraphLaunch then enqueues all their kernels -- at the reference's batch sizes the
+    // host's ~7 us per launch is as long as the kernels themselves (a one-step graph costs more per replay than it saves)
+    for (int sidx = 0; sidx < e->graph_steps && !rc; ++sidx) {
+        e->fh_want = true;
+        rc = gpe_step_begin(e);
+        e->fh_want = false;
+        if (!rc) { e->fu_want = true; rc = gpe_step_backward(e); e->fu_want = false; }
+        if (!rc) rc = gpe_step_update(e);
+        e->fu_done = false;
+    }
     hipError_t st = hipStreamEndCapture(e->cap_stream, &g);
     e->stream = s0;
     e->phase = 0;
@@ -2195,14 +2281,19 @@ static int graph_build(gpe_engine* e) {
 
 int gpe_run(gpe_engine* e, int64_t n_steps) {
     if (!e) return GPE_ERR_INVALID;
-    if (e->use_graph && !e->prof && n_steps >= 8 && e->main.n > 0) {
+    if (e->use_graph && !e->prof && n_steps >= e->graph_steps && e->main.n > 0) {
         if (!e->graph_exec || e->graph_key != graph_key_of(e)) {
             if (graph_build(e) != GPE_OK) { graph_drop(e); e->use_graph = false; }     // fall back to plain launches for good
         }
         if (e->graph_exec) {
-            for (int64_t i = 0; i < n_steps; ++i) HIPCHK(e, hipGraphLaunch(e->graph_exec, e->stream));
+            int64_t done = 0;
+            for (; done + e->graph_steps <= n_steps; done += e->graph_steps) HIPCHK(e, hipGraphLaunch(e->graph_exec, e->stream));
             after_update(e);
             e->phase = 0;
+            for (; done < n_steps; ++done) {          // remainder: plain launches
+                int rc = gpe_step(e, nullptr);
+                if (rc) return rc;
+            }
             return GPE_OK;
         }
     }

@@ -309,6 +309,9 @@ __global__ __launch_bounds__(512, 2) void w_bwd_out(NetDesc nd, const float* __r
 #ifndef GPE_WIDE_STAGGER
 #define GPE_WIDE_STAGGER 0    // w_bwd_map, one-barrier form: 1 = waves 4..7 run the deferred products BEFORE the adjoint phase (measured: 0.705 vs 0.735)
 #endif
+#ifndef GPE_WIDE_SWP
+#define GPE_WIDE_SWP 0        // w_bwd_map: LDS operand fragments of product group g+1 requested BEFORE the products of group g (1-step software pipeline)
+#endif
 #ifndef GPE_WIDE_PRIO_ACT
 #define GPE_WIDE_PRIO_ACT 0   // w_bwd_map: > 0 raises the wave's priority over its activation block, < 0 over its product phases
 #endif
@@ -345,12 +348,19 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
     const float shift = nd.shift;
     const int64_t ntiles = (N + 15) >> 4;
     const int ktile = h * KTL + w;                               // this wave's feature tile of layer j-1
+    // Every HBM / L2 access of the tile loop goes through a buffer descriptor: base + size in SGPRs, ONE per-lane byte offset (lane * 16)
+    // for all of them, the per-(tile, channel, feature tile) part computed on the scalar unit -- plain pointer arithmetic costs two
+    // 64-bit VALU adds per access here (~35 VALU instructions per tile and wave, and every VALU cycle is taken from the fp32 MFMAs)
+    const int wu = __builtin_amdgcn_readfirstlane(w);            // (provably wave-uniform: the descriptor offsets stay in SGPRs)
+    const int ktu = h * KTL + wu;
+    const unsigned lane16 = (unsigned)lane * 16u;
+    constexpr unsigned TILE_B = (unsigned)(C * NT * 256 * sizeof(float));     // one tile of adjoint jets / of one layer's stored jets
     for (int i = threadIdx.x; i < 7 * H + 4; i += NTHR) gb[i] = 0.f; // gb, g0 and go are contiguous
     if constexpr (FIRST || TOP > 0) stage_layer0<H>(w0s, theta, nd, NTHR);
     const float* Wo = w0s + (4 + L - 1) * H;
-    const float* wmap = WpkT + (size_t)(j - 1) * H * H;
+    const buf_t wbuf = buf_make(WpkT + (size_t)(j - 1) * H * H, (unsigned)(H * H * sizeof(float)));
     int wofs = 0;                                               // opaque zero: keeps the weight loads inside the tile loop
-    auto load_w = [&](int nt) { return *reinterpret_cast<const f32x4*>(&wmap[wofs + ((ktile * NT + nt) * 64 + lane) * 4]); };
+    auto load_w = [&](int nt) { return buf_load4(wbuf, lane16, (unsigned)(wofs + (ktu * NT + nt) * 1024)); };
     f32x4 dwacc[RTZ][KTL];                                       // rows 16(w RTZ + rt).., column tiles of this half
 #pragma unroll
     for (int rt = 0; rt < RTZ; ++rt)
@@ -370,23 +380,22 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
     float obv[NO][C];                                            // TOP: the seeds of this lane's point
     auto issue_loads = [&](int64_t t) {
         if constexpr (TOP > 0) {                                 // stored (t, z_k, z_L) of layer j = L-1, own rows; converted at the tile top
+            const buf_t sb = buf_make(stored + ((size_t)t * (L - 1) + (j - 1)) * (C * NT * 256), TILE_B);
 #pragma unroll
             for (int rt = 0; rt < RTZ; ++rt)
 #pragma unroll
-                for (int c = 0; c < C; ++c)
-                    zf[rt][c] = *reinterpret_cast<const f32x4*>(
-                        &stored[(((((size_t)t * (L - 1)) + (j - 1)) * C + c) * NT + w * RTZ + rt) * 256 + lane * 4]);
+                for (int c = 0; c < C; ++c) zf[rt][c] = buf_load4(sb, lane16, (unsigned)((c * NT + wu * RTZ + rt) * 1024));
             const int64_t pm = t * 16 + m;
 #pragma unroll
             for (int o = 0; o < NO; ++o)
 #pragma unroll
                 for (int c = 0; c < C; ++c) obv[o][c] = pm < N ? Ob[((int64_t)c * NO + o) * ld + pm] : 0.f;
         } else {
+            const buf_t zb_ = buf_make(Zin + (size_t)t * (C * NT * 256), TILE_B);
 #pragma unroll
-        for (int rt = 0; rt < RTZ; ++rt)
+            for (int rt = 0; rt < RTZ; ++rt)
 #pragma unroll
-            for (int c = 0; c < C; ++c)
-                zf[rt][c] = *reinterpret_cast<const f32x4*>(&Zin[(((size_t)t * C + c) * NT + w * RTZ + rt) * 256 + lane * 4]);
+                for (int c = 0; c < C; ++c) zf[rt][c] = buf_load4(zb_, lane16, (unsigned)((c * NT + wu * RTZ + rt) * 1024));
         }
         if constexpr (FIRST) {
             const int64_t pm = t * 16 + m;
@@ -458,9 +467,9 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
     float xk[3] = {0.f, 0.f, 0.f};
     auto load_st = [&](int64_t t) {
         if constexpr (!FIRST) {
-            const float* sp = stored + ((((size_t)t * (L - 1) + (j - 2)) * C) * NT + ktile) * 256 + lane * 4;
+            const buf_t sb = buf_make(stored + ((size_t)t * (L - 1) + (j - 2)) * (C * NT * 256), TILE_B);
 #pragma unroll
-            for (int c = 0; c < C; ++c) st[c] = *reinterpret_cast<const f32x4*>(sp + (size_t)c * NT * 256);
+            for (int c = 0; c < C; ++c) st[c] = buf_load4(sb, lane16, (unsigned)((c * NT + ktu) * 1024));
         }
 #pragma unroll
         for (int i = 0; i < W_KCB; ++i) wn[i] = load_w(i);
@@ -471,6 +480,40 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
         f32x4 acc[C];                                            // C independent accumulator chains
 #pragma unroll
         for (int c = 0; c < C; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (GPE_WIDE_SWP) {
+            // one K tile of lookahead on the B fragments: the compiler otherwise re-uses the fragment registers of a chunk for the next
+            // one and can only request them when the last product of the chunk has issued -- every chunk then opens with an exposed
+            // LDS round trip (~150 cycles per 32 products) unless the SIMD partner happens to have products ready
+            f32x4 bfn[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) bfn[c] = *reinterpret_cast<const f32x4*>(&zbuf[(c * NT + 0) * 256 + zfrag]);
+#pragma unroll
+            for (int n0 = 0; n0 < NT; n0 += W_KCB) {
+                f32x4 wv[W_KCB];
+#pragma unroll
+                for (int i = 0; i < W_KCB; ++i) wv[i] = wn[i];
+                if (n0 + W_KCB < NT) {
+#pragma unroll
+                    for (int i = 0; i < W_KCB; ++i) wn[i] = load_w(n0 + W_KCB + i);
+                }
+#pragma unroll
+                for (int i = 0; i < W_KCB; ++i) {
+                    f32x4 bf[C];
+#pragma unroll
+                    for (int c = 0; c < C; ++c) bf[c] = bfn[c];
+                    if (n0 + i + 1 < NT) {
+#pragma unroll
+                        for (int c = 0; c < C; ++c) bfn[c] = *reinterpret_cast<const f32x4*>(&zbuf[(c * NT + n0 + i + 1) * 256 + zfrag]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);          // requests of the next K tile (and weight chunk) before this tile's products
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                        for (int c = 0; c < C; ++c)
+                            acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i][s2], bf[c][s2], acc[c], 0, 0, 0);
+                }
+            }
+        } else
 #pragma unroll
         for (int n0 = 0; n0 < NT; n0 += W_KCB) {
             f32x4 wv[W_KCB];
@@ -504,9 +547,9 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
         act_from_stored<D, E>(st[0], st + 1, st + 1 + D, shift, xa);
         act_adjoint<D, E>(st[0], st + 1, st + 1 + D, acc, zb);
         if constexpr (!FIRST) {
+            const buf_t ob_ = buf_make(Zout + (size_t)tile * (C * NT * 256), TILE_B);
 #pragma unroll
-            for (int c = 0; c < C; ++c)
-                *reinterpret_cast<f32x4*>(&Zout[(((size_t)tile * C + c) * NT + ktile) * 256 + lane * 4]) = zb[c];
+            for (int c = 0; c < C; ++c) buf_store4(zb[c], ob_, lane16, (unsigned)((c * NT + ktu) * 1024));
         } else {      // linear map 0: g0[k][n] (k < dim: dW0[n][k]; k = 3: db0[n])
             const float z0[4] = {zb[0][0], zb[0][1], zb[0][2], zb[0][3]};
             row_reduce4_add(z0, &g0[3 * H + 16 * ktile], m, q);
@@ -547,6 +590,32 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
                 dbacc[rt] += s;
             }
         }
+        if constexpr (GPE_WIDE_SWP) {
+            constexpr int NG = (KTL / 4) * C;                    // product groups: (column chunk of 4 tiles, channel)
+            f32x4 xn[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xn[i] = *reinterpret_cast<const f32x4*>(&xbuf[(0 * KTL + 0 + i) * F_TILE + tr_roff(m, q)]);
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) {
+                const int k0 = (gi / C) * 4, c = gi % C;
+                f32x4 xf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xf[i] = xn[i];
+                if (gi + 1 < NG) {
+                    const int k1 = ((gi + 1) / C) * 4, c1 = (gi + 1) % C;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) xn[i] = *reinterpret_cast<const f32x4*>(&xbuf[(c1 * KTL + k1 + i) * F_TILE + tr_roff(m, q)]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int rt = 0; rt < RTZ; ++rt)
+                            dwacc[rt][k0 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(zt[rt][c][s2], xf[i][s2], dwacc[rt][k0 + i], 0, 0, 0);
+            }
+        } else
 #pragma unroll
         for (int k0 = 0; k0 < KTL; k0 += 4)
 #pragma unroll
@@ -579,7 +648,6 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
         // adjoint products, activation arithmetic and weight-gradient products in a row: the two waves of a SIMD fall out of step by
         // themselves and one's VALU work runs under the other's matrix work.  (The first interval has no deferred products.)
         float *zr = ZB, *zw = ZB + ZSZ, *xw = XT, *xr = XT + XSZ;
-        const int wu = __builtin_amdgcn_readfirstlane(w);
         for (int64_t tile = g; tile < ntiles; tile += G) {
             WSTAMP_ITER;
             asm volatile("" : "+s"(wofs));

@@ -282,11 +282,19 @@ class _PINNBase:
 
     def boundary_loss(self, boundary_points, boundary_values):
         eng = self._get_engine()
-        if not hasattr(eng, "n_local"):
-            eng.bind_points(boundary_points)
-        eng.bind_boundary(boundary_points, boundary_values)
+        if not hasattr(eng, "n_local") or eng.cfg.potential == capi.POT_PRECOMPUTED or eng.cfg.base_kind == capi.BASE_PRECOMPUTED:
+            # the residual launch needs SOME collocation batch: the boundary points themselves (flavours whose potential / base function
+            # are handed over as arrays get arrays of that length; the boundary term uses neither)
+            V = torch.zeros(boundary_points.shape[0], dtype=torch.float32, device=boundary_points.device) \
+                if eng.cfg.potential == capi.POT_PRECOMPUTED else None
+            eng.bind_points(boundary_points, V)
+            self._before_residual(eng, boundary_points)
+        eng.bind_boundary(boundary_points, self._boundary_target(boundary_points, boundary_values))
         sc, _, _ = eng.residual(want_fields=False)
         return torch.tensor(sc["bc"], dtype=torch.float32, device=_device())
+
+    def _boundary_target(self, boundary_points, boundary_values):
+        return boundary_values
 
     def normalization_loss(self, u, dx):
         integral = torch.sum(u ** 2) * dx
@@ -427,6 +435,9 @@ class _GravityWellPINN(_RefinePINN):
 
     def _before_residual(self, eng, inputs):               # per-call surface: the Airy base on the points just bound
         eng.bind_base(*self.base_arrays(_as_np(inputs)[:, 0], self.mode))
+
+    def _boundary_target(self, boundary_points, boundary_values):      # e = base(x_b) + NN(x_b) - values: the array base goes into the target
+        return boundary_values - self.airy_solution(boundary_points, self.mode).reshape(boundary_values.shape)
 
     def pde_loss(self, inputs, predictions, gamma, p, potential_type="gravity_well", precomputed_potential=None):
         if precomputed_potential is None:
@@ -698,6 +709,8 @@ def _refine_train(gamma_values, modes, p, X_train, lb, ub, layers, epochs, tol, 
                 normal_const = float(nn0.max())
                 constant_history[mode] = torch.tensor(normal_const)
             model.perturb_scale = perturb_const / normal_const
+            model._pull()
+            model.start_flat = model._flat.copy()                      # weights this stage started from (after pre-training / warm start)
             eng = model._get_engine(**pot_over, p=int(p), dx=float(dx), lr=float(lr),
                                     sched=capi.SCHED_COSINE_LOSS, T_0=200.0, T_mult=2.0, eta_min=1e-6,
                                     w_bc=10.0, w_norm=20.0, stop_tol=float(tol), stop_patience=2000,
@@ -726,6 +739,7 @@ def _refine_train(gamma_values, modes, p, X_train, lb, ub, layers, epochs, tol, 
                         print(f"Epoch {i}, μ: {h['mu']:.4f}\nTotal Loss: {h['loss']:.6f}, PDE residual: {h['pde']:.6f}, "
                               f"Constraints: {10.0 * h['bc'] + 20.0 * h['norm']:.6f}")
             model._pull()
+            model.history = hist                                       # every epoch's record (the returned histories keep the reference's cadence)
             final_mu = lambda_history[-1] if lambda_history else 0                           # :407 (quirk Q5)
             mu_logs.append((gamma, final_mu))
             model.last_mu = hist[-1]["mu"] if hist else float("nan")
@@ -791,6 +805,8 @@ def _nb_train(gamma_values, powers, modes, X_train, lb, ub, layers, epochs, pote
             else:
                 model.apply(lambda m: _nb_advanced_initialization(m, mode))
             model.gamma = gamma
+            model._pull()
+            model.start_flat = model._flat.copy()                      # weights this stage started from
             eng = model._get_engine(potential=_POT[potential_type], p=int(power), dx=float(dx), lr=float(lr),
                                     sched=capi.SCHED_PLATEAU, factor=0.5, patience=100, min_lr=1e-5,
                                     w_bc=10.0, w_norm=20.0, history_capacity=max(int(epochs), 1))
@@ -808,6 +824,7 @@ def _nb_train(gamma_values, powers, modes, X_train, lb, ub, layers, epochs, pote
                     if i % 500 == 0:
                         print(f"Epoch {i}, Loss: {h['loss']:.6f}, μ: {h['mu']:.4f}")
             model._pull()
+            model.history = hist
             final_mu = lambda_history[-1] if lambda_history else 0
             mu_logs.append((power, final_mu))
             models_by_power[power] = model

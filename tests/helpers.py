@@ -123,3 +123,16 @@ def problem_from_vbeta(fx):
                      bc_target=-fx["base_boundary"]))
     return (go.Problem(potential=go.POT_PRECOMPUTED, base_kind=go.BASE_BOX, box_L=float(fx["ub"]), envelope=go.ENV_SIN, env_L=1.0,
                        **common), dict(V_pre=beta * np.exp(-x[:, 0] ** 2 / 2)))
+
+
+def stage_divergence(pb, start_flat, X, xb, hist, K, sched, lr, **opt):
+    """Engine history `hist` (list of per-epoch records of one driver stage) against the fp64 oracle stepped K epochs from the SAME
+    start weights with the same optimiser settings: per-epoch relative loss error and absolute mu error (arrays of length K).  The
+    oracle trajectory is the yardstick; the divergence grows with k (Adam + clipping amplify rounding), which the callers bound."""
+    st = go.OptState(lr0=float(lr), sched=sched, **opt)
+    _, tr = go.train_steps(pb, st, np.asarray(start_flat, np.float64), np.asarray(X, np.float64), K, np.asarray(xb, np.float64), dtype=np.float64)
+    K = min(K, len(hist))
+    dl = np.array([abs(hist[k]["loss"] - tr[k]["loss"]) / max(abs(tr[k]["loss"]), 1e-30) for k in range(K)])
+    dm = np.array([abs(hist[k]["mu"] - tr[k]["mu"]) for k in range(K)])
+    dlr = np.array([abs(hist[k]["lr"] - tr[k]["lr"]) for k in range(K)])
+    return dl, dm, dlr
