@@ -433,7 +433,7 @@ struct gpe_engine {
     int fh_nslots = 0;             // ... this many triples (= workgroups of that forward launch)
     int64_t fuse_head_tile_min = 32769;   // f_forward (per-wave tiles) runs the head from this many points on (GPE_FUSE_HEAD_TILE_MIN)
     double* head_slots = nullptr;  // [HEAD_SLOTS][4]
-    bool fuse_update = true;       // small P, whole steps: the last-arriving workgroup of the slab reduction runs the update (k_reduce_update; GPE_FUSE_UPDATE=0)
+    bool fuse_update = false;      // small P, whole steps: the last-arriving workgroup of the slab reduction runs the update (k_reduce_update; opt-in GPE_FUSE_UPDATE=1)
     bool fu_want = false;          // gpe_step / graph capture in progress: reduction and update are enqueued back to back
     bool fu_done = false;          // this step's update already ran inside the slab reduction
     unsigned* upd_ticket = nullptr;
@@ -467,6 +467,8 @@ struct gpe_engine {
     // gpe_run replays one captured step (hipGraph) while every by-value launch argument is unchanged
     bool use_graph = false;
     int graph_steps = 8;           // steps captured per graph (GPE_GRAPH_STEPS)
+    bool graph_forced = false;     // GPE_GRAPH set: at every batch size; otherwise only up to graph_max_points
+    int64_t graph_max_points = 16384;
     hipStream_t cap_stream = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     std::vector<char> graph_key;
@@ -1414,8 +1416,10 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
         const char* envf6 = getenv("GPE_FUSE_HEAD_MAX");
         if (envf6) e->fuse_head_max = atoll(envf6);
         if (ok && e->fuse_head) ok = alloc((void**)&e->head_slots, (size_t)HEAD_SLOTS * 4 * sizeof(double));
+        // opt-in: measured 1 us SLOWER than the two launches at 2 048 .. 65 536 points (profiles/r04/small_batch.txt) -- 200 workgroups'
+        // tickets on one address (~12 ns apiece) and the write-through hand-off cost what the saved launch gives
         const char* envfu = getenv("GPE_FUSE_UPDATE");
-        e->fuse_update = !(envfu && atoi(envfu) == 0);
+        e->fuse_update = envfu && atoi(envfu) != 0;
         if (ok && e->fuse_update) ok = alloc((void**)&e->upd_ticket, 64);
 
     }
@@ -1519,7 +1523,11 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
         const char* envb = getenv("GPE_MERGE_BC");
         e->merge_bc = !envb || atoi(envb) != 0;
         const char* envg = getenv("GPE_GRAPH");
-        e->use_graph = envg && atoi(envg) != 0;    // opt-in: measured 6 % slower than plain launches on ROCm 7.2 (141 vs 133 us/step)
+        // gpe_run replays captured graphs of graph_steps steps each.  Round 4: ONE graph launch per 8 steps takes the host from 31 to
+        // 3 us per step at 2 048 points with the step time unchanged (35.5 us: the GPU is the bound); a one-step graph is slower (44.8 us).
+        // Default: on for batches up to graph_max_points (where the host thread was ~90 % busy enqueueing); GPE_GRAPH=0 / 1 forces it
+        e->use_graph = envg ? atoi(envg) != 0 : true;
+        e->graph_forced = envg != nullptr;
         const char* envgs = getenv("GPE_GRAPH_STEPS");
         if (envgs && atoi(envgs) >= 1 && atoi(envgs) <= 64) e->graph_steps = atoi(envgs);
         const char* envq = getenv("GPE_SIDE_STREAM");
@@ -2281,7 +2289,7 @@ static int graph_build(gpe_engine* e) {
 
 int gpe_run(gpe_engine* e, int64_t n_steps) {
     if (!e) return GPE_ERR_INVALID;
-    if (e->use_graph && !e->prof && n_steps >= e->graph_steps && e->main.n > 0) {
+    if (e->use_graph && !e->prof && n_steps >= e->graph_steps && e->main.n > 0 && (e->graph_forced || e->main.n <= e->graph_max_points)) {
         if (!e->graph_exec || e->graph_key != graph_key_of(e)) {
             if (graph_build(e) != GPE_OK) { graph_drop(e); e->use_graph = false; }     // fall back to plain launches for good
         }

@@ -856,11 +856,12 @@ __global__ __launch_bounds__(H * 4, 2) void f_forward_coop(NetDesc nd, const flo
             if constexpr (H == 128 && GPE_FCOOP_ALT_PRIO) __builtin_amdgcn_s_setprio(0);
             const f32x4 tt = gpe_tanh(acc[0]);
             act_from_stored<D, E>(tt, acc + 1, acc + 1 + D, shift, a);
-            if (store_acts) {
-                float* sp = stored + ((((size_t)tile * (L - 1) + (j - 1)) * C) * NT + w) * 256 + lane * 4;
-                *reinterpret_cast<f32x4*>(sp) = tt;
+            if (store_acts) {      // through a per-(tile, layer) buffer descriptor: no 64-bit VALU address arithmetic per store
+                const buf_t sb = buf_make(stored + ((size_t)tile * (L - 1) + (j - 1)) * (C * NT * 256), (unsigned)(C * NT * 256 * sizeof(float)));
+                const int wu = __builtin_amdgcn_readfirstlane(w);
+                buf_store4(tt, sb, (unsigned)lane * 16u, (unsigned)(wu * 1024));
 #pragma unroll
-                for (int c = 1; c < C; ++c) *reinterpret_cast<f32x4*>(sp + (size_t)c * NT * 256) = acc[c];
+                for (int c = 1; c < C; ++c) buf_store4(acc[c], sb, (unsigned)lane * 16u, (unsigned)((c * NT + wu) * 1024));
             }
         }
         // output layer: this slice's part of the dot products, reduced over the 4 q-lanes of a point, then over the waves

@@ -77,6 +77,9 @@ __global__ __launch_bounds__(512, 2) void w_forward(NetDesc nd, const float* __r
     int wofs = 0;                                               // opaque zero: keeps the (tile-invariant) weight loads inside the loop
     WSTAMP_INIT;
     const bool hi_even = w < 4;
+    // buffer descriptors for the streamed weight rows and the stored jets (as in w_bwd_map: no per-access VALU address arithmetic)
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    const unsigned lane16 = (unsigned)lane * 16u;
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         asm volatile("" : "+s"(wofs));                         // (an opaque OFFSET, not an opaque pointer: the loads stay global_load)
@@ -95,10 +98,8 @@ __global__ __launch_bounds__(512, 2) void w_forward(NetDesc nd, const float* __r
         }
         for (int j = 1; j < L; ++j) {
             WSTAMP_ITER;
-            const float* Wp = Wpk + (size_t)(j - 1) * H * H + wofs;
-            auto load_w = [&](int rt, int kt) {
-                return *reinterpret_cast<const f32x4*>(&Wp[(((w * RT + rt) * NT + kt) * 64 + lane) * 4]);
-            };
+            const buf_t wbuf = buf_make(Wpk + (size_t)(j - 1) * H * H, (unsigned)(H * H * sizeof(float)));
+            auto load_w = [&](int rt, int kt) { return buf_load4(wbuf, lane16, (unsigned)(wofs + ((wu * RT + rt) * NT + kt) * 1024)); };
             f32x4 wn[W_KC][RT];
 #pragma unroll
             for (int i = 0; i < W_KC; ++i)
@@ -158,10 +159,10 @@ __global__ __launch_bounds__(512, 2) void w_forward(NetDesc nd, const float* __r
                 const f32x4 tt = gpe_tanh(acc[rt][0]);
                 act_from_stored<D, E>(tt, acc[rt] + 1, acc[rt] + 1 + D, shift, a[rt]);
                 if (store_acts) {
-                    float* sp = stored + ((((size_t)tile * (L - 1) + (j - 1)) * C) * NT + w * RT + rt) * 256 + lane * 4;
-                    *reinterpret_cast<f32x4*>(sp) = tt;
+                    const buf_t sb = buf_make(stored + ((size_t)tile * (L - 1) + (j - 1)) * (C * NT * 256), (unsigned)(C * NT * 256 * sizeof(float)));
+                    buf_store4(tt, sb, lane16, (unsigned)((wu * RT + rt) * 1024));
 #pragma unroll
-                    for (int c = 1; c < C; ++c) *reinterpret_cast<f32x4*>(sp + (size_t)c * NT * 256) = acc[rt][c];
+                    for (int c = 1; c < C; ++c) buf_store4(acc[rt][c], sb, lane16, (unsigned)((c * NT + wu * RT + rt) * 1024));
                 }
             }
         }

@@ -742,9 +742,9 @@ def test_update_kernel_forms_are_bit_identical(layers, sym, sched):
     lb, tb = run({"GPE_UPDATE_CACHE": "0"})
     np.testing.assert_array_equal(la, lb)
     np.testing.assert_array_equal(ta, tb)
-    # round 4: by default (no symmetry batch) the update runs inside the slab-reduction launch, in the workgroup that arrives last
-    # (k_reduce_update); GPE_FUSE_UPDATE=0 is the two-launch form.  Same operations, same order: bit for bit.
-    lf, tf = run({"GPE_FUSE_UPDATE": "0"})
+    # round 4: the update inside the slab-reduction launch, in the workgroup that arrives last (k_reduce_update, opt-in GPE_FUSE_UPDATE=1;
+    # taken when there is no symmetry batch).  Same operations, same order: bit for bit.
+    lf, tf = run({"GPE_FUSE_UPDATE": "1"})
     np.testing.assert_array_equal(la, lf)
     np.testing.assert_array_equal(ta, tf)
     lc, tc = run({"GPE_UPDATE_MULTI_MIN": "1"})
