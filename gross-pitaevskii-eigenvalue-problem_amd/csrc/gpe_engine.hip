@@ -71,6 +71,7 @@ static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1
 #define UPD_MULTI_MIN 32768
 struct UpdSnap { double sums[S_COUNT]; double lsums[LS_COUNT]; OptDev od; double part[UPD_G]; };
 GPE_DEV int upd_chunk(int P) { return (((P + UPD_G - 1) / UPD_G) + 3) & ~3; }
+static int upd_chunk_host(int P) { return (((P + UPD_G - 1) / UPD_G) + 3) & ~3; }
 __global__ __launch_bounds__(1024) void k_update_part(int P, const float* __restrict__ grad, const double* __restrict__ sums,
                                                        const double* __restrict__ lsums, const OptDev* __restrict__ od,
                                                        UpdSnap* __restrict__ snap) {
@@ -110,6 +111,21 @@ template <bool SC1>
 GPE_DEV float grad_load(const float* p) {
     if constexpr (SC1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else return *p;
+}
+
+// W_j[n][kk] of a hidden-hidden map -> its slots in the two packed copies (pack_weight_element inverted): the update SCATTERS the new
+// weights instead of a gather pass behind a barrier
+GPE_DEV void scatter_pack(const NetDesc& nd, int H, int i, float th, float* __restrict__ Wpk, float* __restrict__ WpkT) {
+    const int lg = H == 64 ? 6 : (H == 32 ? 5 : (H == 128 ? 7 : 8)), NT = H >> 4, maps = nd.n_lin - 2;
+    for (int j = 1; j <= maps; ++j) {
+        const int e = i - nd.offW[j];
+        if (e >= 0 && e < H * H) {
+            const int n = e >> lg, kk = e & (H - 1);
+            const int nt = n >> 4, kt = kk >> 4;
+            Wpk[(((j - 1) * NT + nt) * NT + kt) * 256 + ((n & 15) + 16 * ((kk & 15) >> 2)) * 4 + (kk & 3)] = th;
+            WpkT[(((j - 1) * NT + kt) * NT + nt) * 256 + ((kk & 15) + 16 * ((n & 15) >> 2)) * 4 + (n & 3)] = th;
+        }
+    }
 }
 
 template <bool MULTI, bool SC1 = false>
@@ -266,7 +282,6 @@ GPE_DEV void update_core(int P, float* __restrict__ theta, float* __restrict__ a
     if (!s_skip && cached) {
         const float coef = s_coef, ss = s_ss, b2s = s_b2s;
         const float b1 = oc.beta1, b2 = oc.beta2, eps = oc.eps;
-        const int lg = H == 64 ? 6 : (H == 32 ? 5 : (H == 128 ? 7 : 8)), NT = H >> 4, maps = nd.n_lin - 2;
 #pragma unroll
         for (int k = 0; k < REG_E; ++k) {
             const int i = threadIdx.x + k * 1024;
@@ -275,17 +290,7 @@ GPE_DEV void update_core(int P, float* __restrict__ theta, float* __restrict__ a
                 adam_element(cg[k], m, v, th, coef, ss, b2s, b1, b2, eps);
                 theta[i] = th;
                 am[i] = m; av[i] = v;
-                if (pack_mode == 2 && n_pack > 0) {             // W_j[n][kk] of a hidden-hidden map -> its slots in Wpk / WpkT (pack_weight_element inverted)
-                    for (int j = 1; j <= maps; ++j) {
-                        const int e = i - nd.offW[j];
-                        if (e >= 0 && e < H * H) {
-                            const int n = e >> lg, kk = e & (H - 1);
-                            const int nt = n >> 4, kt = kk >> 4;
-                            Wpk[(((j - 1) * NT + nt) * NT + kt) * 256 + ((n & 15) + 16 * ((kk & 15) >> 2)) * 4 + (kk & 3)] = th;
-                            WpkT[(((j - 1) * NT + kt) * NT + nt) * 256 + ((kk & 15) + 16 * ((n & 15) >> 2)) * 4 + (n & 3)] = th;
-                        }
-                    }
-                }
+                if (pack_mode == 2 && n_pack > 0) scatter_pack(nd, H, i, th, Wpk, WpkT);
             }
         }
     } else if (!s_skip) {
@@ -296,6 +301,7 @@ GPE_DEV void update_core(int P, float* __restrict__ theta, float* __restrict__ a
             adam_element(grad_load<SC1>(&grad[i]), m, v, th, coef, ss, b2s, b1, b2, eps);
             theta[i] = th;
             am[i] = m; av[i] = v;
+            if (MULTI && pack_mode == 2 && n_pack > 0) scatter_pack(nd, H, i, th, Wpk, WpkT);      // (small networks on the split update)
         }
     }
     // Prepare the NEXT step, so that it can start with its forward kernel: the step sums are consumed (thread 0 read them
@@ -380,6 +386,61 @@ __global__ __launch_bounds__(1024) void k_reduce_update(const float* __restrict_
                              n_dbl, nullptr, nullptr, pack_mode);
 }
 
+// Slab reduction of SMALL parameter vectors for whole steps (gpe_step / gpe_run), in the partition of the multi-workgroup update: UPD_G
+// workgroups, workgroup b owns the parameters [b chunk, (b+1) chunk), chunk = upd_chunk(P) <= 1024.  Besides the gradient it leaves what
+// k_update_part would: the partial sums of |g|^2 (fixed order) and the snapshot of the step sums / optimiser state -- so the update that
+// follows is k_update<true> on UPD_G workgroups, a handful of elements per thread, instead of ONE workgroup walking all P parameters through
+// a chain of dependent L2 round trips (10.4 us of a 40.5 us step at 4 000 points).  Threads: column = t % chunk, slab group = t / chunk.
+__global__ __launch_bounds__(1024) void k_grad_reduce_part(const float* __restrict__ gslab, int nslab, int Ppad, int P, float* __restrict__ grad,
+                                                            const float* __restrict__ add, const double* __restrict__ tail_dsc,
+                                                            const double* __restrict__ sums, const double* __restrict__ lsums,
+                                                            const OptDev* __restrict__ od, UpdSnap* __restrict__ snap) {
+    __shared__ float red[1024];
+    __shared__ double red2[16];
+    const int chunk = upd_chunk(P), lo = blockIdx.x * chunk;
+    const int ng = 1024 / chunk;                                  // slab groups (>= 1: chunk <= 1024 is checked by the launcher)
+    const int col = threadIdx.x % chunk, grp = threadIdx.x / chunk;
+    const int i = lo + col;
+    float s = 0.f;
+    if (grp < ng && i < P) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;            // four loads in flight per thread (fixed order of the final sum)
+        int b = grp;
+        for (; b + 3 * ng < nslab; b += 4 * ng) {
+            s0 += gslab[(size_t)b * Ppad + i];
+            s1 += gslab[(size_t)(b + ng) * Ppad + i];
+            s2 += gslab[(size_t)(b + 2 * ng) * Ppad + i];
+            s3 += gslab[(size_t)(b + 3 * ng) * Ppad + i];
+        }
+        for (; b < nslab; b += ng) s0 += gslab[(size_t)b * Ppad + i];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    double gsq = 0.0;
+    if (grp == 0 && i < P) {
+        float t = 0.f;
+        for (int k = 0; k < ng; ++k) t += red[k * chunk + col];
+        if (add) t += add[i];
+        grad[i] = t;
+        gsq = (double)t * (double)t;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) gsq += __shfl_down(gsq, o, 64);
+    if ((threadIdx.x & 63) == 0) red2[threadIdx.x >> 6] = gsq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int k = 0; k < 16; ++k) tot += red2[k];
+        snap->part[blockIdx.x] = tot;
+    }
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < S_COUNT) snap->sums[threadIdx.x] = sums[threadIdx.x];
+        if (threadIdx.x < LS_COUNT) snap->lsums[threadIdx.x] = lsums[threadIdx.x];
+        if (threadIdx.x == 64) snap->od = *od;
+        if (threadIdx.x == 65) { grad[P + GT_SUM_R2] = (float)tail_dsc[0]; grad[P + GT_MSE_SE2] = (float)tail_dsc[2]; }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 struct Batch {
     Pts pts = {nullptr, nullptr, 0};   // point coordinates [n][dim]: rows [0,na) from a, the rest from b (merged boundary points)
@@ -437,6 +498,9 @@ struct gpe_engine {
     bool fu_want = false;          // gpe_step / graph capture in progress: reduction and update are enqueued back to back
     bool fu_done = false;          // this step's update already ran inside the slab reduction
     unsigned* upd_ticket = nullptr;
+    bool split_update = true;      // small P, whole steps: slab reduction in the update's partition + k_update<true> on UPD_G workgroups (GPE_SPLIT_UPDATE=0)
+    UpdSnap* upd_snap_small = nullptr;
+    bool fu_parts = false;         // this step's slab reduction left partial norms + snapshot for the multi-workgroup update
     UpdSnap* upd_snap = nullptr;   // multi-workgroup update (P >= UPD_MULTI_MIN): partial norms + snapshot of sums / optimiser state
     gpe_scalars *hist = nullptr, *last = nullptr;
     int cap = 65536;
@@ -766,7 +830,7 @@ static bool use_pipe(gpe_engine* e, int C);
 // the kernel forms the seeds itself and k_seed_pde is not launched
 static bool seed_in_reverse(gpe_engine* e) {
     return e->fuse_seed && e->path == GPE_PATH_FUSED && !e->wide && e->nd.n_out == 1 && !e->cfg.complex_psi && e->ph.n_orth == 0 &&
-           e->cfg.w_riesz == 0.f && e->cfg.w_sym == 0.f && e->main.C >= 3 && e->main.n > 0 && e->main.n <= e->fuse_seed_max &&
+           e->cfg.w_riesz == 0.f && e->cfg.w_sym == 0.f && e->main.C >= 3 && e->main.n > 0 && e->n_pde <= e->fuse_seed_max &&
            use_pipe(e, e->main.C) && bwd_kind(e, e->main) == 3;
 }
 static int bwd_kind(gpe_engine* e, const Batch& b) {
@@ -1086,6 +1150,11 @@ static int mlp_backward(gpe_engine* e, Batch& b, bool close = false, bool assign
                                e->ph, e->oc, e->od, e->hist, e->cap, e->last, bc_count(e), e->nd, e->H, e->Wpk, e->WpkT, n_pack, e->dbl,
                                (int)(S_COUNT + LS_COUNT + 4), ((e->fwd_b6 || e->bwd_b6 || e->H > 64) ? 1 : 2));
             e->fu_done = true;
+        } else if (close && assign && e->fu_want && e->split_update && e->upd_snap_small && !e->upd_snap && !e->comm && !e->ext_exchange &&
+                   !e->fwd_b6 && !e->bwd_b6 && e->H <= 64) {
+            hipLaunchKernelGGL(k_grad_reduce_part, dim3(UPD_G), dim3(1024), 0, e->stream, e->gslab, nred, e->Ppad, e->P, e->grad, add,
+                               (const double*)e->dsc(), (const double*)e->sums(), (const double*)e->lsums(), (const OptDev*)e->od, e->upd_snap_small);
+            e->fu_parts = true;
         } else
         hipLaunchKernelGGL(k_grad_reduce, dim3(cdiv(e->P, 64)), dim3(1024), 0, e->stream, e->gslab, nred, e->Ppad,
                            e->P, e->grad, add, close ? (const double*)e->dsc() : (const double*)nullptr, assign ? 1 : 0);
@@ -1421,6 +1490,9 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
         const char* envfu = getenv("GPE_FUSE_UPDATE");
         e->fuse_update = envfu && atoi(envfu) != 0;
         if (ok && e->fuse_update) ok = alloc((void**)&e->upd_ticket, 64);
+        const char* envsu = getenv("GPE_SPLIT_UPDATE");
+        e->split_update = !(envsu && atoi(envsu) == 0);
+        if (ok && e->split_update && !e->upd_snap && upd_chunk_host(e->P) <= 1024) ok = alloc((void**)&e->upd_snap_small, sizeof(UpdSnap));
 
     }
     if (ok && e->path == GPE_PATH_FUSED) {
@@ -1564,7 +1636,7 @@ void gpe_destroy(gpe_engine* e) {
     free_batch(e->main); free_batch(e->bc); free_batch(e->sym); free_batch(e->aux); free_batch(e->mse);
     for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
     if (e->ext_exchange) { e->grad = nullptr; e->dbl = nullptr; }
-    void* ps[] = {e->theta, e->am, e->av, e->grad, e->dbl, e->od, e->hist, e->last, (void*)e->orth_dev, e->Wpk, e->WpkT, e->gslab, e->gslab_bc, e->grad_bc, (void*)e->upd_snap, (void*)e->head_slots, (void*)e->upd_ticket};
+    void* ps[] = {e->theta, e->am, e->av, e->grad, e->dbl, e->od, e->hist, e->last, (void*)e->orth_dev, e->Wpk, e->WpkT, e->gslab, e->gslab_bc, e->grad_bc, (void*)e->upd_snap, (void*)e->head_slots, (void*)e->upd_ticket, (void*)e->upd_snap_small};
     for (void* p : ps) if (p) (void)hipFree(p);
     delete e;
 }
@@ -1784,7 +1856,7 @@ int gpe_step_begin(gpe_engine* e) {
     if (e->cfg.base_mode >= 0 && e->cfg.base_kind == GPE_BASE_PRECOMPUTED && !e->orth_host[4])
         FAIL(e, GPE_ERR_STATE, "precomputed base requested but gpe_bind_base was not called");
     int rc;
-    e->fh_now = false; e->seedf_now = false; e->fu_done = false;      // per-step flags: a step that failed half-way must not leave them behind
+    e->fh_now = false; e->seedf_now = false; e->fu_done = false; e->fu_parts = false;      // per-step flags: a step that failed half-way must not leave them behind
     e->phase = 0;
     if ((rc = launch_begin(e))) return rc;
     if ((rc = bc_fork(e, true))) return rc;
@@ -1900,6 +1972,18 @@ int gpe_step_update(gpe_engine* e) {
     if (!e) return GPE_ERR_INVALID;
     if (e->phase != 2) FAIL(e, GPE_ERR_STATE, "step_update without step_backward");
     if (e->fu_done) { e->fu_done = false; after_update(e); e->phase = 0; return GPE_OK; }      // the slab reduction's last workgroup ran it
+    if (e->fu_parts) {          // the slab reduction left partial norms + snapshot: the update on UPD_G workgroups, new weights scattered into the packed copies
+        e->fu_parts = false;
+        const int n_pack = (e->nd.n_lin - 2) * e->H * e->H;
+        hipLaunchKernelGGL(k_update<true>, dim3(UPD_G), dim3(1024), 0, e->stream, e->P, e->theta, e->am, e->av, (const float*)e->grad,
+                           (const double*)e->sums(), (const double*)e->lsums(), e->ph, e->oc, e->od, e->hist, e->cap, e->last, bc_count(e), 1, 0,
+                           e->nd, e->H, e->Wpk, e->WpkT, n_pack, e->dbl, (int)(S_COUNT + LS_COUNT + 4), (double*)nullptr,
+                           (const UpdSnap*)e->upd_snap_small, 2);
+        HIPCHK(e, hipGetLastError());
+        after_update(e);
+        e->phase = 0;
+        return GPE_OK;
+    }
     launch_update(e, e->grad, e->sums(), e->lsums(), bc_count(e), 1, 0, nullptr);
     HIPCHK(e, hipGetLastError());
     after_update(e);
@@ -2224,7 +2308,7 @@ int gpe_step(gpe_engine* e, gpe_scalars* out) {
     e->fu_want = true;                            // ... and backward and update: the update may ride in the slab reduction
     rc = gpe_step_backward(e);
     e->fu_want = false;
-    if (rc) { e->fu_done = false; return rc; }
+    if (rc) { e->fu_done = false; e->fu_parts = false; return rc; }
     if ((rc = gpe_step_update(e))) return rc;
     if (out) return gpe_read_scalars(e, out);
     return GPE_OK;
@@ -2272,7 +2356,7 @@ static int graph_build(gpe_engine* e) {
         e->fh_want = false;
         if (!rc) { e->fu_want = true; rc = gpe_step_backward(e); e->fu_want = false; }
         if (!rc) rc = gpe_step_update(e);
-        e->fu_done = false;
+        e->fu_done = false; e->fu_parts = false;
     }
     hipError_t st = hipStreamEndCapture(e->cap_stream, &g);
     e->stream = s0;

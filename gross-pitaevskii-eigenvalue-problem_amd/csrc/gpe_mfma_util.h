@@ -16,6 +16,9 @@ GPE_DEV buf_t buf_make(const void* base, unsigned bytes) {
 GPE_DEV f32x4 buf_load4(buf_t r, unsigned lane_bytes, unsigned uni_bytes) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_bytes, uni_bytes, 0));
 }
+GPE_DEV float buf_load1(buf_t r, unsigned lane_bytes, unsigned uni_bytes) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane_bytes, uni_bytes, 0));
+}
 GPE_DEV void buf_store4(f32x4 v, buf_t r, unsigned lane_bytes, unsigned uni_bytes) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, lane_bytes, uni_bytes, 0);
 }

@@ -360,6 +360,7 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
     if constexpr (FIRST || TOP > 0) stage_layer0<H>(w0s, theta, nd, NTHR);
     const float* Wo = w0s + (4 + L - 1) * H;
     const buf_t wbuf = buf_make(WpkT + (size_t)(j - 1) * H * H, (unsigned)(H * H * sizeof(float)));
+    const buf_t obuf = buf_make(Ob, (unsigned)((size_t)C * NO * ld * sizeof(float)));      // TOP: the seeds [C][n_out][ld]
     int wofs = 0;                                               // opaque zero: keeps the weight loads inside the tile loop
     auto load_w = [&](int nt) { return buf_load4(wbuf, lane16, (unsigned)(wofs + (ktu * NT + nt) * 1024)); };
     f32x4 dwacc[RTZ][KTL];                                       // rows 16(w RTZ + rt).., column tiles of this half
@@ -370,6 +371,23 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
     float dbacc[RTZ];
 #pragma unroll
     for (int rt = 0; rt < RTZ; ++rt) dbacc[rt] = 0.f;
+    // H = 128 (register room): the small gradients of the launch -- db_j, and dW_out / db_out (TOP), dW_0 / db_0 (FIRST) -- are summed PER LANE
+    // over all the tiles of the workgroup and reduced across the point lanes ONCE after the loop; per tile that was a DPP / bpermute
+    // reduction plus an LDS atomic (~100 cycles of the wave each) for every one of them
+    constexpr bool LANEACC = (H == 128);
+    float gwoacc[NO][RTZ][4], gboacc[NO], g0acc[4][4];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+        gboacc[o] = 0.f;
+#pragma unroll
+        for (int rt = 0; rt < RTZ; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gwoacc[o][rt][r] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g0acc[k][r] = 0.f;
     __syncthreads();
 
     // The wave's rows of zbar_j (HBM, needed first thing in a tile) are requested one tile AHEAD, before the weight-gradient
@@ -387,10 +405,14 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
 #pragma unroll
                 for (int c = 0; c < C; ++c) zf[rt][c] = buf_load4(sb, lane16, (unsigned)((c * NT + wu * RTZ + rt) * 1024));
             const int64_t pm = t * 16 + m;
+            const unsigned pm4 = (unsigned)(pm * 4);             // (ld * C * NO * 4 bytes < 4 GB: checked by the launcher)
 #pragma unroll
             for (int o = 0; o < NO; ++o)
 #pragma unroll
-                for (int c = 0; c < C; ++c) obv[o][c] = pm < N ? Ob[((int64_t)c * NO + o) * ld + pm] : 0.f;
+                for (int c = 0; c < C; ++c) {
+                    const float v = buf_load1(obuf, pm4, (unsigned)((c * NO + o) * (unsigned)ld * 4u));
+                    obv[o][c] = pm < N ? v : 0.f;
+                }
         } else {
             const buf_t zb_ = buf_make(Zin + (size_t)t * (C * NT * 256), TILE_B);
 #pragma unroll
@@ -447,14 +469,22 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
                 }
                 if (h == 0) {
 #pragma unroll
-                    for (int o = 0; o < NO; ++o) row_reduce4_add(gwo[o], &go[o * H + 16 * (w * RTZ + rt)], m, q);
+                    for (int o = 0; o < NO; ++o) {
+                        if constexpr (LANEACC) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) gwoacc[o][rt][r] += gwo[o][r];
+                        } else row_reduce4_add(gwo[o], &go[o * H + 16 * (w * RTZ + rt)], m, q);
+                    }
                 }
             }
             if (h == 0 && w == 0) {
 #pragma unroll
                 for (int o = 0; o < NO; ++o) {
-                    const float gbo = row_sum16(obv[o][0]);
-                    if (lane == 0) atomicAdd(&go[2 * H + o], gbo);
+                    if constexpr (LANEACC) gboacc[o] += obv[o][0];
+                    else {
+                        const float gbo = row_sum16(obv[o][0]);
+                        if (lane == 0) atomicAdd(&go[2 * H + o], gbo);
+                    }
                 }
             }
         }
@@ -553,7 +583,10 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
             for (int c = 0; c < C; ++c) buf_store4(zb[c], ob_, lane16, (unsigned)((c * NT + ktu) * 1024));
         } else {      // linear map 0: g0[k][n] (k < dim: dW0[n][k]; k = 3: db0[n])
             const float z0[4] = {zb[0][0], zb[0][1], zb[0][2], zb[0][3]};
-            row_reduce4_add(z0, &g0[3 * H + 16 * ktile], m, q);
+            if constexpr (LANEACC) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g0acc[3][r] += z0[r];
+            } else row_reduce4_add(z0, &g0[3 * H + 16 * ktile], m, q);
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 if (k < D || (D == 0 && k < dim)) {
@@ -563,7 +596,10 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
                         v[r] = zb[0][r] * xk[k];
                         if constexpr (C > 1) { if (k < D) v[r] += zb[(1 + k) < C ? (1 + k) : 0][r]; }
                     }
-                    row_reduce4_add(v, &g0[k * H + 16 * ktile], m, q);
+                    if constexpr (LANEACC) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) g0acc[k][r] += v[r];
+                    } else row_reduce4_add(v, &g0[k * H + 16 * ktile], m, q);
                 }
             }
         }
@@ -586,9 +622,11 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
             }
             if (h == 0) {                                        // bias gradient of map j: row sums of the value channel
                 float s = (zt[rt][0][0] + zt[rt][0][1]) + (zt[rt][0][2] + zt[rt][0][3]);
-                s += __shfl_xor(s, 16, 64);
-                s += __shfl_xor(s, 32, 64);
-                dbacc[rt] += s;
+                if constexpr (!LANEACC) {
+                    s += __shfl_xor(s, 16, 64);
+                    s += __shfl_xor(s, 32, 64);
+                }
+                dbacc[rt] += s;                                  // (LANEACC: the sum over the four point groups q follows after the loop)
             }
         }
         if constexpr (GPE_WIDE_SWP) {
@@ -719,6 +757,37 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 slab[nd.offW[j] + (16 * (w * RTZ + rt) + 4 * q + r) * H + 16 * (h * KTL + kt) + m] = dwacc[rt][kt][r];
+    if constexpr (LANEACC) {
+#pragma unroll
+        for (int rt = 0; rt < RTZ; ++rt) {
+            float sv = dbacc[rt];
+            sv += __shfl_xor(sv, 16, 64);
+            sv += __shfl_xor(sv, 32, 64);
+            dbacc[rt] = sv;
+        }
+        if constexpr (TOP > 0) {
+            if (g < ntiles && h == 0) {
+#pragma unroll
+                for (int o = 0; o < NO; ++o)
+#pragma unroll
+                    for (int rt = 0; rt < RTZ; ++rt) row_reduce4_add(gwoacc[o][rt], &go[o * H + 16 * (w * RTZ + rt)], m, q);
+                if (w == 0) {
+#pragma unroll
+                    for (int o = 0; o < NO; ++o) {
+                        const float gbo = row_sum16(gboacc[o]);
+                        if (lane == 0) atomicAdd(&go[2 * H + o], gbo);
+                    }
+                }
+            }
+        }
+        if constexpr (FIRST) {
+            if (g < ntiles) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k == 3 || k < D || (D == 0 && k < dim)) row_reduce4_add(g0acc[k], &g0[k * H + 16 * ktile], m, q);
+            }
+        }
+    }
     if (h == 0 && q == 0) {
 #pragma unroll
         for (int rt = 0; rt < RTZ; ++rt) slab[nd.offB[j] + 16 * (w * RTZ + rt) + m] = dbacc[rt];

@@ -107,6 +107,7 @@ static void launch_bwd(const WideCall& a) {
 
 int wide_backward(const WideCall& a) {
     if (!W_NOUT2 && a.nd.n_out != 1) return -1;
+    if ((size_t)a.C * a.nd.n_out * (size_t)a.ld * sizeof(float) >= ((size_t)1 << 32)) return -1;      // the seed array goes through one buffer descriptor
 #define CASE_B(HH, CC, EE) if (a.H == HH && a.C == CC && a.E == EE) { launch_bwd<HH, CC, EE>(a); return (int)hipGetLastError(); }
     W_FOR_SHAPES(CASE_B)
 #undef CASE_B

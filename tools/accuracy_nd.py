@@ -35,6 +35,9 @@ ap.add_argument("--w-norm-final", type=float, default=100.0, help="normalisation
 ap.add_argument("--w-bc", type=float, default=10.0)
 ap.add_argument("--w-riesz", type=float, default=1.0, help="weight of the variational (normalised-state) energy term; 0: residual loss only")
 ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--big-grid", default="", help="e.g. 64,128,64: after the schedule, continue on THIS grid (BASELINE's per-GPU size) for --big-epochs epochs "
+                                               "at the low end of the learning-rate ladder, and evaluate mu there (same weights, fresh Adam)")
+ap.add_argument("--big-epochs", type=int, default=3000)
 ap.add_argument("--out", default="")
 a = ap.parse_args()
 cs = CASES[a.case]
@@ -115,6 +118,40 @@ for si, g in enumerate(gam):
     rows.append(dict(gamma=g, epochs=ne, mu=sc["mu"], loss=sc["loss"], pde=sc["pde"], norm=sc["integral"], lr=sc["lr"], riesz=sc["riesz"]))
     print(f"stage {si}: gamma {g:8.2f} mu {sc['mu']:.6f} E {sc['riesz']:.6f} loss {sc['loss']:.3e} pde {sc['pde']:.3e} int {sc['integral']:.6f} lr {sc['lr']:.1e} "
           f"({time.time() - t0:.0f} s)", flush=True)
+big = None
+if a.big_grid:
+    # the per-GPU batch of the BASELINE configuration: same box, finer grid; the trained weights move over, the quadrature weight changes
+    nb = [int(v) for v in a.big_grid.split(",")]
+    assert len(nb) == d
+    axb = [np.linspace(-half, half, k) for k in nb]
+    Xb = np.stack([m.ravel() for m in np.meshgrid(*axb, indexing="ij")], axis=1).astype(np.float32)
+    dvb = float(np.prod([ax[1] - ax[0] for ax in axb]))
+    cfg_b = gpe_pinn.GPEConfig(layers=cs["layers"], gamma=cs["g"], p=3, kinetic_coeff=0.5, pot_scale=0.5, omega=tuple(cs["omega"]) + (1.0,) * (3 - d),
+                               dx=dvb, w_bc=a.w_bc, w_norm=a.w_norm_final, lr=a.lr * 0.01, sched=capi.SCHED_CONST, history_capacity=8,
+                               w_riesz=a.w_riesz, riesz_kind=capi.RIESZ_VARIATIONAL)
+    eng_b = gpe_pinn.Engine(cfg_b)
+    eng_b.set_params(eng.get_params())
+    mu_small = rows[-1]["mu"]
+    eng.close()
+    eng = eng_b
+    xdb = torch.as_tensor(Xb, device="cuda")
+    eng.bind_points(xdb)
+    eng.bind_boundary(torch.as_tensor(xb, device="cuda"))
+    sc0 = eng.residual(want_fields=False)[0]
+    print(f"big grid {nb} ({Xb.shape[0]} points): mu of the small-grid state {sc0['mu']:.6f} (on its own grid {mu_small:.6f})", flush=True)
+    tb = time.time()
+    for frac, lr in ((0.5, a.lr * 0.01), (0.3, a.lr * 0.003), (0.2, a.lr * 0.001)):
+        eng.set_lr(lr)
+        left = int(a.big_epochs * frac)
+        while left > 0:
+            n_run = min(left, 500)
+            eng.run(n_run)
+            left -= n_run
+            scp = eng.read_scalars()
+            print(f"   big grid: lr {lr:.1e} mu {scp['mu']:.6f} pde {scp['pde']:.3e} int {scp['integral']:.6f} ({time.time() - t0:.0f} s)", flush=True)
+    sc = eng.read_scalars()
+    big = dict(grid=nb, points=int(Xb.shape[0]), epochs=a.big_epochs, mu_before=sc0["mu"], seconds=time.time() - tb)
+    rows.append(dict(gamma=cs["g"], epochs=a.big_epochs, mu=sc["mu"], loss=sc["loss"], pde=sc["pde"], norm=sc["integral"], lr=sc["lr"], riesz=sc["riesz"]))
 wall = time.time() - t0
 mu = rows[-1]["mu"]
 # mu of the NORMALISED state u / sqrt(int), from the three scalars of the last stage: with A = (kinetic + potential) / int and
@@ -149,7 +186,7 @@ out = dict(case=a.case, workload=cs["workload"], layers=cs["layers"], points=int
            schedule=dict(pretrain=a.pretrain, epochs=a.epochs, final=a.final, stages=a.stages, lr=a.lr, w_norm=a.w_norm, w_bc=a.w_bc,
                          w_riesz=a.w_riesz, w_norm_final=a.w_norm_final,
                          scheduler="constant lr per stage, fresh Adam per stage; last stage lr x (1, 0.3, 0.1, 0.03, 0.01, 0.003, 0.001)"),
-           energy=rows[-1]["riesz"], energy_ref=truth["energy"])
+           energy=rows[-1]["riesz"], energy_ref=truth["energy"], big_grid=big)
 path = a.out or os.path.join(ROOT, "gpurun_out", f"accuracy_{cs['workload']}.json")
 os.makedirs(os.path.dirname(path), exist_ok=True)
 json.dump(out, open(path, "w"), indent=1)
