@@ -498,7 +498,7 @@ struct gpe_engine {
     bool fu_want = false;          // gpe_step / graph capture in progress: reduction and update are enqueued back to back
     bool fu_done = false;          // this step's update already ran inside the slab reduction
     unsigned* upd_ticket = nullptr;
-    bool split_update = true;      // small P, whole steps: slab reduction in the update's partition + k_update<true> on UPD_G workgroups (GPE_SPLIT_UPDATE=0)
+    bool split_update = false;     // small P, whole steps: slab reduction in the update's partition + k_update<true> on UPD_G workgroups (opt-in GPE_SPLIT_UPDATE=1)
     UpdSnap* upd_snap_small = nullptr;
     bool fu_parts = false;         // this step's slab reduction left partial norms + snapshot for the multi-workgroup update
     UpdSnap* upd_snap = nullptr;   // multi-workgroup update (P >= UPD_MULTI_MIN): partial norms + snapshot of sums / optimiser state
@@ -1490,8 +1490,10 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
         const char* envfu = getenv("GPE_FUSE_UPDATE");
         e->fuse_update = envfu && atoi(envfu) != 0;
         if (ok && e->fuse_update) ok = alloc((void**)&e->upd_ticket, 64);
+        // opt-in as well: measured EQUAL to the single-workgroup update (35.8 vs 35.7 us at 2 048 points, 41.4 vs 41.0 at 4 000,
+        // profiles/r04/small_batch.txt) -- at these sizes a dependent launch costs ~4 us whatever it runs, and the update's own chain is short
         const char* envsu = getenv("GPE_SPLIT_UPDATE");
-        e->split_update = !(envsu && atoi(envsu) == 0);
+        e->split_update = envsu && atoi(envsu) != 0;
         if (ok && e->split_update && !e->upd_snap && upd_chunk_host(e->P) <= 1024) ok = alloc((void**)&e->upd_snap_small, sizeof(UpdSnap));
 
     }

@@ -19,8 +19,14 @@ GPE_DEV f32x4 buf_load4(buf_t r, unsigned lane_bytes, unsigned uni_bytes) {
 GPE_DEV float buf_load1(buf_t r, unsigned lane_bytes, unsigned uni_bytes) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane_bytes, uni_bytes, 0));
 }
+// HAZARD (found the hard way, round 4: value-only batches with the shifted tanh): a 16-byte buffer store whose uniform offset sits in an
+// SGPR, followed IMMEDIATELY by a VALU instruction that overwrites its data registers (the compiler forms a = t + shift in place right
+// behind the store of t), stores the NEW values on gfx950.  hipcc's hazard recogniser pads this pattern only for stores WITHOUT a register
+// soffset.  The empty-bodied wait below names the stored registers as inputs, so nothing can overwrite them before two wait states
+// have passed (2 cycles per store; the stores of the hot loops are 1 in ~16 instructions).
 GPE_DEV void buf_store4(f32x4 v, buf_t r, unsigned lane_bytes, unsigned uni_bytes) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, lane_bytes, uni_bytes, 0);
+    asm volatile("s_nop 1" ::"v"(v));
 }
 
 // Transposition tiles: 16 x 16 floats, row pitch 16, the column index XOR-swizzled with 8 in rows 8..15.  Written point-on-lane

@@ -591,6 +591,31 @@ def _as_np(X):
     return X.detach().cpu().numpy() if isinstance(X, torch.Tensor) else np.asarray(X)
 
 
+class _History:
+    """Every epoch's record of one driver stage, kept on the returned model (`model.history[k]["loss" | "mu" | "lr" | ...]`): column
+    arrays instead of one dict per epoch (the 201-stage experiment records 400 000 epochs)."""
+
+    def __init__(self, rows):
+        self._keys = list(rows[0].keys()) if rows else []
+        self._cols = {k: np.array([r[k] for r in rows], dtype=np.float64) for k in self._keys}
+        self._n = len(rows)
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, k):
+        if isinstance(k, str):
+            return self._cols[k]
+        if k < 0:
+            k += self._n
+        if not 0 <= k < self._n:
+            raise IndexError(k)
+        return {key: float(col[k]) for key, col in self._cols.items()}
+
+    def __iter__(self):
+        return (self[k] for k in range(self._n))
+
+
 def _history(eng: Engine, first: int, last: int, chunk: int = 8192):
     out = []
     s = first
@@ -739,7 +764,7 @@ def _refine_train(gamma_values, modes, p, X_train, lb, ub, layers, epochs, tol, 
                         print(f"Epoch {i}, μ: {h['mu']:.4f}\nTotal Loss: {h['loss']:.6f}, PDE residual: {h['pde']:.6f}, "
                               f"Constraints: {10.0 * h['bc'] + 20.0 * h['norm']:.6f}")
             model._pull()
-            model.history = hist                                       # every epoch's record (the returned histories keep the reference's cadence)
+            model.history = _History(hist)                             # every epoch's record (the returned histories keep the reference's cadence)
             final_mu = lambda_history[-1] if lambda_history else 0                           # :407 (quirk Q5)
             mu_logs.append((gamma, final_mu))
             model.last_mu = hist[-1]["mu"] if hist else float("nan")
@@ -824,7 +849,7 @@ def _nb_train(gamma_values, powers, modes, X_train, lb, ub, layers, epochs, pote
                     if i % 500 == 0:
                         print(f"Epoch {i}, Loss: {h['loss']:.6f}, μ: {h['mu']:.4f}")
             model._pull()
-            model.history = hist
+            model.history = _History(hist)
             final_mu = lambda_history[-1] if lambda_history else 0
             mu_logs.append((power, final_mu))
             models_by_power[power] = model

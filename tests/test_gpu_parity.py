@@ -738,7 +738,7 @@ def test_update_kernel_forms_are_bit_identical(layers, sym, sched):
         eng.close()
         return np.array(tr), th
 
-    one = {"GPE_SPLIT_UPDATE": "0"}                               # the single-workgroup update kernel
+    one = {}                                                      # default: slab reduction + the single-workgroup update kernel
     la, ta = run(one)
     lb, tb = run(dict(one, GPE_UPDATE_CACHE="0"))
     np.testing.assert_array_equal(la, lb)
@@ -750,12 +750,12 @@ def test_update_kernel_forms_are_bit_identical(layers, sym, sched):
     np.testing.assert_array_equal(ta, tf)
     lc, tc = run(dict(one, GPE_UPDATE_MULTI_MIN="1"))
     assert np.abs(lc - la).max() <= 1e-5 * np.abs(la).max() and np.abs(tc - ta).max() < 1e-5
-    # round 4 default for whole steps of small networks without a symmetry batch: slab reduction in the update's partition
-    # (k_grad_reduce_part: gradient + partial |g|^2 + snapshot) and the update on 64 workgroups with the new weights scattered into the
-    # packed copies -- |g|^2 and the slab sums are added in another order: equal to rounding, and repeatable bit for bit
-    ld, td = run({})
+    # round 4, opt-in GPE_SPLIT_UPDATE=1 (whole steps of small networks without a symmetry batch): slab reduction in the update's
+    # partition (k_grad_reduce_part: gradient + partial |g|^2 + snapshot) and the update on 64 workgroups with the new weights scattered
+    # into the packed copies -- |g|^2 and the slab sums are added in another order: equal to rounding, and repeatable bit for bit
+    ld, td = run({"GPE_SPLIT_UPDATE": "1"})
     assert np.abs(ld - la).max() <= 1e-5 * np.abs(la).max() and np.abs(td - ta).max() < 1e-5
-    ld2, td2 = run({})
+    ld2, td2 = run({"GPE_SPLIT_UPDATE": "1"})
     np.testing.assert_array_equal(ld, ld2)
     np.testing.assert_array_equal(td, td2)
 
