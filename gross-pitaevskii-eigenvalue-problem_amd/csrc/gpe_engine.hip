@@ -513,6 +513,7 @@ struct gpe_engine {
     bool fwd_b6 = false;                          // f_forward_b6: H x H maps as six bf16 MFMA products per fp32 product (H <= 64; GPE_FWD_B6)
     bool bwd_b6 = false;                          // f_backward_coop<..., B6>: the adjoint products the same way (H <= 64; GPE_BWD_B6)
     int coop_wg_per_cu = 2;                       // cooperative reverse kernels at H <= 64: persistent workgroups per CU (tuning: GPE_COOP_WG_PER_CU)
+    int fwd_wg_per_cu = 2;                        // per-wave-tile forward kernel: persistent workgroups per CU (tuning: GPE_FWD_WG_PER_CU; 3 needs a -DGPE_FWD_WAVES=3 build)
     bool bwd_pipe = true;                         // cooperative reverse kernel in its one-barrier-per-map form (f_backward_pipe; H <= 64; GPE_PIPE)
     bool bwd_racc = false;                        // reverse kernel keeps the H x H weight gradients in registers (1 wave/SIMD)
     int nslab_g = 16;                             // H = 128: number of global-atomic gradient slabs
@@ -715,7 +716,7 @@ static bool head_fusable_coop(gpe_engine* e) {
 }
 // ... by the per-wave-tile forward kernel (large batches; k_seed_pde, or the seed-forming reverse kernel, adds the triples)
 static bool head_fusable_tile(gpe_engine* e) {
-    return head_class(e) && !fwd_coop(e, e->main) && !e->fwd_b6 && e->main.n >= e->fuse_head_tile_min && fused_grid(e, e->main.n, 4, 2) <= HEAD_SLOTS;
+    return head_class(e) && !fwd_coop(e, e->main) && !e->fwd_b6 && e->main.n >= e->fuse_head_tile_min && fused_grid(e, e->main.n, 4, e->fwd_wg_per_cu) <= HEAD_SLOTS;
 }
 static bool head_fusable(gpe_engine* e) { return head_fusable_coop(e) || head_fusable_tile(e); }
 static bool head_in_forward(gpe_engine* e) { return e->fuse_head && e->fh_want && head_fusable(e); }
@@ -1026,7 +1027,7 @@ static int mlp_forward(gpe_engine* e, Batch& b, bool store) {
     if (e->path == GPE_PATH_FUSED) {
         int rc = ensure_packed(e);
         if (rc) return rc;
-        unsigned grid = fused_grid(e, b.n, 4, 2);
+        unsigned grid = fused_grid(e, b.n, 4, e->fwd_wg_per_cu);
         if (mark) prof_mark(e, 0, true);
         if (e->wide_fwd) {
             const int wr = wide_forward(wide_call(e, b), store ? 1 : 0);
@@ -1356,7 +1357,7 @@ int gpe_active_kernels(gpe_engine* e, char* buf, size_t n) {
     int sf = 0, sb = 0;
     if (e->path == GPE_PATH_FUSED && !e->wide && e->H <= 64) {
         const int64_t ntiles = (b.n + 15) / 16, g2 = 2 * (int64_t)e->num_cu;
-        if (!fwd_coop(e, b) && !e->fwd_b6 && e->fwd_share > 0 && fused_grid(e, b.n, 4, 2) == (unsigned)g2 && ntiles >= 4 * e->share_min_tiles * g2)
+        if (!fwd_coop(e, b) && !e->fwd_b6 && e->fwd_share > 0 && fused_grid(e, b.n, 4, e->fwd_wg_per_cu) == (unsigned)g2 && ntiles >= 4 * e->share_min_tiles * g2)
             sf = e->fwd_share;
         if (bwd_kind(e, b) == 3 && use_pipe(e, b.C) && !seed_in_reverse(e) && e->pipe_share > 0 &&
             fused_grid(e, b.n, 1, e->coop_wg_per_cu) == (unsigned)g2 && ntiles >= e->share_min_tiles * g2)
@@ -1518,6 +1519,8 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
             e->bwd_pipe = !envp || atoi(envp) != 0;
             const char* envw = getenv("GPE_COOP_WG_PER_CU");
             if (envw && atoi(envw) >= 1 && atoi(envw) <= 2) e->coop_wg_per_cu = atoi(envw);
+            const char* envfw = getenv("GPE_FWD_WG_PER_CU");
+            if (envfw && atoi(envfw) >= 1 && atoi(envfw) <= 4) e->fwd_wg_per_cu = atoi(envfw);
             const char* envc = getenv("GPE_COOP");
             e->coop = envc ? atoi(envc) : 1;          // measured: faster than the per-wave-tile kernels at every batch size
             const char* envm = getenv("GPE_COOP_MAX_TILES");
@@ -1863,7 +1866,7 @@ int gpe_step_begin(gpe_engine* e) {
     if ((rc = launch_begin(e))) return rc;
     if ((rc = bc_fork(e, true))) return rc;
     const bool fh = head_in_forward(e);
-    if (fh) e->fh_nslots = (int)(head_fusable_coop(e) ? fused_grid(e, e->main.n, 1, 2) : fused_grid(e, e->main.n, 4, 2));
+    if (fh) e->fh_nslots = (int)(head_fusable_coop(e) ? fused_grid(e, e->main.n, 1, 2) : fused_grid(e, e->main.n, 4, e->fwd_wg_per_cu));
     e->fh_now = fh;
     rc = mlp_forward(e, e->main, true);
     if (!rc && !fh) rc = launch_head_pde(e);
