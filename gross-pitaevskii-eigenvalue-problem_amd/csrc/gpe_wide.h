@@ -310,6 +310,10 @@ __global__ __launch_bounds__(512, 2) void w_bwd_out(NetDesc nd, const float* __r
 #ifndef GPE_WIDE_STAGGER
 #define GPE_WIDE_STAGGER 0    // w_bwd_map, one-barrier form: 1 = waves 4..7 run the deferred products BEFORE the adjoint phase (measured: 0.705 vs 0.735)
 #endif
+#ifndef GPE_WIDE_TOP_EARLY
+#define GPE_WIDE_TOP_EARLY 0  // w_bwd_map, top launch, one-barrier form: the next tile's seeds / stored jets requested BEFORE the adjoint phase and its output-layer block
+                              // (activation jets, W_out products, activation adjoint) placed in front of the wave's own weight-gradient products instead of behind them
+#endif
 #ifndef GPE_WIDE_SWP
 #define GPE_WIDE_SWP 0        // w_bwd_map: LDS operand fragments of product group g+1 requested BEFORE the products of group g (1-step software pipeline)
 #endif
@@ -436,7 +440,7 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
     WSTAMP_INIT;
     // zbar_j of a tile, own rows, into a z buffer.  TOP: formed here from the seeds and the stored activations of the last hidden layer
     // (dW_out / db_out on the way); otherwise it is what issue_loads fetched.
-    auto publish = [&](float* zbuf) {
+    auto publish_compute = [&]() {
         if constexpr (TOP > 0) {                                 // output layer: dW_out, db_out, zbar_{L-1} = act-adjoint(W_out^T Ob), own rows
 #pragma unroll
             for (int rt = 0; rt < RTZ; ++rt) {
@@ -488,11 +492,14 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
                 }
             }
         }
+    };
+    auto publish_store = [&](float* zbuf) {
 #pragma unroll
         for (int rt = 0; rt < RTZ; ++rt)
 #pragma unroll
             for (int c = 0; c < C; ++c) *reinterpret_cast<f32x4*>(&zbuf[(c * NT + w * RTZ + rt) * 256 + zfrag]) = zf[rt][c];
     };
+    auto publish = [&](float* zbuf) { publish_compute(); publish_store(zbuf); };
     f32x4 st[C];
     f32x4 wn[W_KCB];
     float xk[3] = {0.f, 0.f, 0.f};
@@ -707,6 +714,20 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
                 adjoint_phase(tile, zr, xw);
                 if (more) load_st(tile + G);
                 WSTAMP(5);
+                if (more) publish(zw);
+            } else if (TOP > 0 && GPE_WIDE_TOP_EARLY) {
+                // top launch: the next tile's seeds and stored jets are requested a phase earlier, so that the output-layer block that turns them
+                // into zbar_{L-1} can stand IN FRONT of the wave's weight-gradient products (the compiler is free to mix the two) instead of behind
+                // them, where all eight waves ran it at the same time with the matrix pipe idle
+                if (more) issue_loads(tile + G);
+                adjoint_phase(tile, zr, xw);
+                if (more) load_st(tile + G);
+                __builtin_amdgcn_sched_barrier(0);
+                WSTAMP(5);
+                if (more) publish_compute();
+                if (tile != g) product_phase(zw, xr);
+                WSTAMP(7);
+                if (more) publish_store(zw);
             } else {
                 adjoint_phase(tile, zr, xw);
                 if (more) { issue_loads(tile + G); load_st(tile + G); }  // in flight behind the products below
@@ -714,8 +735,8 @@ __global__ __launch_bounds__(512, 2) void w_bwd_map(NetDesc nd, int j, const flo
                 WSTAMP(5);
                 if (tile != g) product_phase(zw, xr);            // previous tile: own rows of zw, all of xr (the first interval has none)
                 WSTAMP(7);
+                if (more) publish(zw);                           // next tile's zbar_j over the rows just read
             }
-            if (more) publish(zw);                               // next tile's zbar_j over the rows just read
             float* t0 = zr; zr = zw; zw = t0;
             t0 = xr; xr = xw; xw = t0;
         }
