@@ -1326,7 +1326,7 @@ int gpe_active_kernels(gpe_engine* e, char* buf, size_t n) {
     char f[160], r[160];
     const int maps = e->nd.n_lin - 2;
     if (e->path == GPE_PATH_FUSED && e->wide) {
-        if (e->wide_fwd) snprintf(f, sizeof f, "w_forward<%d,%d,%d,%d>", e->H, b.C, b.E, e->nd.n_out);
+        if (e->wide_fwd) snprintf(f, sizeof f, "%s<%d,%d,%d,%d>", wide_forward_kernel(e->H), e->H, b.C, b.E, e->nd.n_out);
         else if (fwd_coop(e, b)) snprintf(f, sizeof f, "f_forward_coop<%d,%d,%d,%d,%d>", e->H, b.C, b.E, e->nd.n_out, maps > 5 ? 5 : maps);
         else snprintf(f, sizeof f, "f_forward<%d,%d,%d,%d,l2>", e->H, b.C, b.E, e->nd.n_out);
         snprintf(r, sizeof r, "%d x w_bwd_map<%d,%d,%d,%d> (output layer fused into the top map)", maps, e->H, b.C, b.E, e->H / 128);

@@ -202,6 +202,134 @@ __global__ __launch_bounds__(512, 2) void w_forward(NetDesc nd, const float* __r
     WSTAMP_FLUSH(0);
 }
 
+// ---- forward, several point tiles per pass (round 4; H = 128) -----------------------------------------------------------------------
+// w_forward spends one barrier pair per layer on 128 products per wave at H = 128 (640 at H = 256, where it reaches 0.88 of the peak): here a workgroup takes
+// TP tiles (16 TP points) through the network together -- every streamed weight fragment serves TP tiles, a barrier pair covers 128 TP products per wave,
+// the activation block of one tile runs between the products of another.  Same numerics, same stored-activation format (per tile) as w_forward.
+template <int H, int C, int E, int NOUT, int TP>
+__global__ __launch_bounds__(512, 2) void w_forward_mt(NetDesc nd, const float* __restrict__ theta,
+                                                       const float* __restrict__ Wpk, Pts x, float* __restrict__ stored,
+                                                       float* __restrict__ O, int64_t N, int64_t ld, int store_acts) {
+    constexpr int D = C - 1 - E, NT = H / 16, NTHR = 64 * W_NW;
+    static_assert(NT == W_NW, "one feature tile per wave (H = 128)");
+    extern __shared__ __attribute__((aligned(16))) float lds_w[];
+    float* w0s = lds_w;
+    float* AB = w0s + ((small_count(nd, H) + 3) & ~3);          // [TP][C][NT][256]
+    float* OP = AB + TP * C * NT * 256;                         // [TP][W_NW][NOUT][C][16]
+    const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4, w = threadIdx.x >> 6;
+    const int L = nd.n_lin - 1;
+    const int dim = nd.dim;
+    const float shift = nd.shift;
+    const int64_t ntiles = (N + 15) >> 4;
+    const int64_t npass = (ntiles + TP - 1) / TP;
+    stage_layer0<H>(w0s, theta, nd, NTHR);
+    __syncthreads();
+    const float* Wo = w0s + (4 + L - 1) * H;
+    const float* bo = w0s + (4 + L - 1 + NOUT) * H;
+    int wofs = 0;                                               // opaque zero: keeps the (pass-invariant) weight loads inside the loop
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    const unsigned lane16 = (unsigned)lane * 16u;
+
+    for (int64_t pass = blockIdx.x; pass < npass; pass += gridDim.x) {
+        asm volatile("" : "+s"(wofs));
+        const int64_t tile0 = pass * TP;
+        f32x4 a[TP][C];
+#pragma unroll
+        for (int t = 0; t < TP; ++t) {                          // layer 0 (K = dim <= 3): VALU, own feature tile
+            const int64_t pm = (tile0 + t) * 16 + m;
+            const int64_t pl = pm < N ? pm : N - 1;
+            float xv[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) if (k < dim) xv[k] = pts_at(x, pl, dim, k);
+            f32x4 st[C];
+            layer0_st<H, C, E>(w0s, xv, w, q, st);
+            act_from_stored<D, E>(st[0], st + 1, st + 1 + D, shift, a[t]);
+        }
+        for (int j = 1; j < L; ++j) {
+            const buf_t wbuf = buf_make(Wpk + (size_t)(j - 1) * H * H, (unsigned)(H * H * sizeof(float)));
+            auto load_w = [&](int kt) { return buf_load4(wbuf, lane16, (unsigned)(wofs + (wu * NT + kt) * 1024)); };
+            f32x4 wn[W_KC];
+#pragma unroll
+            for (int i = 0; i < W_KC; ++i) wn[i] = load_w(i);   // first chunk: in flight across the barriers
+            __syncthreads();                                    // every wave is done reading AB (previous layer / pass)
+#pragma unroll
+            for (int t = 0; t < TP; ++t)
+#pragma unroll
+                for (int c = 0; c < C; ++c) *reinterpret_cast<f32x4*>(&AB[((t * C + c) * NT + w) * 256 + lane * 4]) = a[t][c];
+            __syncthreads();
+            f32x4 acc[TP][C];
+            const f32x4 bj = *reinterpret_cast<const f32x4*>(&w0s[(4 + (j - 1)) * H + 16 * w + 4 * q]);
+#pragma unroll
+            for (int t = 0; t < TP; ++t) {
+                acc[t][0] = bj;
+#pragma unroll
+                for (int c = 1; c < C; ++c) acc[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int k0 = 0; k0 < NT; k0 += W_KC) {
+                f32x4 wv[W_KC];
+#pragma unroll
+                for (int i = 0; i < W_KC; ++i) wv[i] = wn[i];
+                if (k0 + W_KC < NT) {
+#pragma unroll
+                    for (int i = 0; i < W_KC; ++i) wn[i] = load_w(k0 + W_KC + i);
+                    __builtin_amdgcn_sched_barrier(0);          // the next chunk's loads are issued BEFORE this chunk's products
+                }
+#pragma unroll
+                for (int i = 0; i < W_KC; ++i)
+#pragma unroll
+                    for (int t = 0; t < TP; ++t) {
+                        f32x4 bf[C];
+#pragma unroll
+                        for (int c = 0; c < C; ++c) bf[c] = *reinterpret_cast<const f32x4*>(&AB[((t * C + c) * NT + k0 + i) * 256 + lane * 4]);
+#pragma unroll
+                        for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                            for (int c = 0; c < C; ++c)
+                                acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i][s2], bf[c][s2], acc[t][c], 0, 0, 0);
+                    }
+            }
+#pragma unroll
+            for (int t = 0; t < TP; ++t) {
+                const f32x4 tt = gpe_tanh(acc[t][0]);
+                act_from_stored<D, E>(tt, acc[t] + 1, acc[t] + 1 + D, shift, a[t]);
+                if (store_acts && tile0 + t < ntiles) {
+                    const buf_t sb = buf_make(stored + ((size_t)(tile0 + t) * (L - 1) + (j - 1)) * (C * NT * 256), (unsigned)(C * NT * 256 * sizeof(float)));
+                    buf_store4(tt, sb, lane16, (unsigned)(wu * 1024));
+#pragma unroll
+                    for (int c = 1; c < C; ++c) buf_store4(acc[t][c], sb, lane16, (unsigned)((c * NT + wu) * 1024));
+                }
+            }
+        }
+        // output layer: this wave's part of the dot products, reduced over the 4 q-lanes of a point, then over the waves
+#pragma unroll
+        for (int t = 0; t < TP; ++t)
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(&Wo[o * H + 16 * w + 4 * q]);
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    float v = wv[0] * a[t][c][0];
+#pragma unroll
+                    for (int r = 1; r < 4; ++r) v = fmaf(wv[r], a[t][c][r], v);
+                    v += __shfl_xor(v, 16, 64);
+                    v += __shfl_xor(v, 32, 64);
+                    if (q == 0) OP[(((t * W_NW + w) * NOUT + o) * C + c) * 16 + m] = v;
+                }
+            }
+        __syncthreads();
+        for (int i = threadIdx.x; i < TP * NOUT * C * 16; i += NTHR) {
+            const int pmi = i & 15, oc = (i >> 4) % (NOUT * C), t = i / (NOUT * C * 16), c = oc % C, o = oc / C;
+            float v = (c == 0) ? bo[o] : 0.f;
+#pragma unroll
+            for (int ww = 0; ww < W_NW; ++ww) v += OP[(((t * W_NW + ww) * NOUT + o) * C + c) * 16 + pmi];
+            const int64_t p = (tile0 + t) * 16 + pmi;
+            if (p < N) O[((int64_t)c * NOUT + o) * ld + p] = v;
+        }
+        // OP is rewritten only after the two barriers of the next pass's first hidden map (L >= 2)
+    }
+}
+
 // workgroup b of a launch of G*NSPLIT workgroups -> (half h, tile group g).  Workgroups are dealt round-robin over the 8 XCDs
 // (b and b+8 share one): the NSPLIT workgroups of a tile group are placed on the same XCD so that the second read of zbar_j is
 // served by that XCD's L2.  Speed only -- any mapping is correct.

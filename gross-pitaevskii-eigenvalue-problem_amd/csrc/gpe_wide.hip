@@ -63,8 +63,50 @@ static void launch_fwd(const WideCall& a, int store) {
                            a.stored, a.O, a.N, a.ld, store);
 }
 
+// H = 128: several tiles per pass (w_forward_mt).  TP by LDS: TP C NT 1 KiB + small operands <= 160 KB -> 4 tiles up to C = 4, 3 at C = 5, 2 at C = 7
+template <int CC, int EE, int TP>
+static void launch_fwd_mt(const WideCall& a, int store) {
+    constexpr int HH = 128, NT = HH / 16;
+    const int64_t ntiles = (a.N + 15) / 16, npass = (ntiles + TP - 1) / TP;
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(npass, a.num_cu));
+    const size_t lds = (small4(a.nd, HH) + (size_t)TP * CC * NT * 256 + (size_t)TP * W_NW * a.nd.n_out * CC * 16) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)w_forward_mt<HH, CC, EE, 1, TP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (W_NOUT2) (void)hipFuncSetAttribute((const void*)w_forward_mt<HH, CC, EE, W_NOUT2 ? 2 : 1, TP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    if (a.nd.n_out == 1)
+        hipLaunchKernelGGL((w_forward_mt<HH, CC, EE, 1, TP>), dim3(grid), dim3(512), lds, a.stream, a.nd, a.theta, a.Wpk, a.pts, a.stored, a.O, a.N, a.ld, store);
+    else
+        hipLaunchKernelGGL((w_forward_mt<HH, CC, EE, W_NOUT2 ? 2 : 1, TP>), dim3(grid), dim3(512), lds, a.stream, a.nd, a.theta, a.Wpk, a.pts, a.stored, a.O,
+                           a.N, a.ld, store);
+}
+
+static int wide_fwd_mt() {
+#ifdef GPE_FAST_BUILD
+    return 0;
+#else
+    // opt-in (GPE_WIDE_FWD_MT=1): measured SLOWER than w_forward at H = 128 -- cfg3 forward 0.644 against 0.610 ms (f_forward_coop<128>: 0.580),
+    // cfg4 1.56-1.58 against 1.52-1.54 (1.46), profiles/r04/wide_forward_mt_ab.txt
+    static const int mt = [] { const char* v = getenv("GPE_WIDE_FWD_MT"); return v ? atoi(v) : 0; }();
+    return mt;
+#endif
+}
+const char* wide_forward_kernel(int H) { return (H == 128 && wide_fwd_mt()) ? "w_forward_mt" : "w_forward"; }
+
 int wide_forward(const WideCall& a, int store) {
     if (!W_NOUT2 && a.nd.n_out != 1) return -1;
+#ifndef GPE_FAST_BUILD
+    if (a.H == 128 && wide_fwd_mt()) {
+        if (a.C == 1 && a.E == 0) { launch_fwd_mt<1, 0, 4>(a, store); return (int)hipGetLastError(); }
+        if (a.C == 3 && a.E == 1) { launch_fwd_mt<3, 1, 4>(a, store); return (int)hipGetLastError(); }
+        if (a.C == 4 && a.E == 1) { launch_fwd_mt<4, 1, 4>(a, store); return (int)hipGetLastError(); }
+        if (a.C == 5 && a.E == 1) { launch_fwd_mt<5, 1, 3>(a, store); return (int)hipGetLastError(); }
+        if (a.C == 5 && a.E == 2) { launch_fwd_mt<5, 2, 3>(a, store); return (int)hipGetLastError(); }
+        if (a.C == 7 && a.E == 3) { launch_fwd_mt<7, 3, 2>(a, store); return (int)hipGetLastError(); }
+    }
+#endif
 #define CASE_F(HH, CC, EE) if (a.H == HH && a.C == CC && a.E == EE) { launch_fwd<HH, CC, EE>(a, store); return (int)hipGetLastError(); }
     W_FOR_SHAPES(CASE_F) W_FOR_FWD_ONLY(CASE_F)
 #undef CASE_F

@@ -21,4 +21,5 @@ bool wide_shape_ok(int H);
 int wide_groups(int H, int64_t N, int num_cu);
 void wide_init();                                        // dynamic-LDS attributes, once per process
 int wide_forward(const WideCall& a, int store_acts);     // hipSuccess (0), or -1: channel pair not compiled
+const char* wide_forward_kernel(int H);                  // "w_forward_mt" (H = 128: several tiles per pass) or "w_forward"
 int wide_backward(const WideCall& a);                    // launches w_bwd_out + one w_bwd_map per hidden->hidden map

@@ -28,6 +28,32 @@ def test_workloads_are_consistent():
         assert flat.shape == (n_par,) and np.isfinite(flat).all()
 
 
+def test_in_run_oracle_check_covers_the_timed_batch_where_the_oracle_fits():
+    """bench.parity_points: the whole bound batch for the headline workload (and every workload whose numpy oracle fits the time budget),
+    else the largest 4096-multiple slice inside it; stale profile records are labelled."""
+    import bench
+    for name, full in (("ns_2d_4x64", True), ("cfg1_1d_4x32", True), ("cfg2_1d_4x64", True), ("cfg3_2d_5x128", True), ("cfg5_3d_6x256", False)):
+        wl = bench.WORKLOADS[name]
+        n = int(np.prod(wl["grid"]))
+        k = bench.parity_points(wl["layers"], n, 90.0)
+        assert (k == n) == full, (name, k, n)
+        assert min(4096, n) <= k <= n and (k == n or k % 4096 == 0)
+    rec, path, stale = bench.load_profile_json("no_such_record.json")
+    assert rec is None and path is None and stale is None
+    rec, path, stale = bench.load_profile_json("traffic_ns_2d_4x64.json")
+    assert rec is not None and path.startswith("profiles/") and (stale is None) == path.startswith(f"profiles/{bench.PROFILE_ROUND}/")
+
+
+def test_driver_history_container():
+    from gpe_pinn.surface import _History
+    h = _History([{"loss": 1.0, "mu": 2.0, "lr": 1e-3}, {"loss": 0.5, "mu": 2.5, "lr": 1e-3}])
+    assert len(h) == 2 and h[1] == {"loss": 0.5, "mu": 2.5, "lr": 1e-3} and h[-1]["mu"] == 2.5
+    assert [r["loss"] for r in h] == [1.0, 0.5] and list(h["mu"]) == [2.0, 2.5]
+    with pytest.raises(IndexError):
+        h[2]
+    assert len(_History([])) == 0
+
+
 def test_gpus_n_launches_n_ranks():
     """`python bench.py --gpus N` without RANK in the environment starts N worker processes (RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_* set) before anything touches the GPU; with RANK set (torchrun) it is itself a worker."""

@@ -1097,3 +1097,16 @@ def test_golden_vary_beta_oplevel(name):
         assert abs(sc["loss"] - float(fx["total"])) < 1e-3 * float(fx["total"])
         assert H.rel_err(eng.get_grad(), fx["grad0"]) < 1e-3
         eng.close()
+
+
+def test_multi_tile_wide_forward_kernel_matches_oracle():
+    """w_forward_mt (H = 128, several point tiles per pass; opt-in GPE_WIDE=1 GPE_WIDE_FWD_MT=1 -- measured slower than the defaults, kept as a
+    recorded experiment): the H = 128 oracle cases through it, in a child process (the wide unit reads its switch once per process);
+    N = 300 / 1000 give ragged last passes for TP = 3 and 4."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPE_WIDE="1", GPE_WIDE_FWD_MT="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-m", "gpu", "-x",
+                        "-k", "test_step_matches_oracle and 128 and fused"], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
