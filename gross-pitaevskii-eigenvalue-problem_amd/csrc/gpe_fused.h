@@ -41,6 +41,9 @@
 #endif
 #define GPE_COOP_PRIO 1      // s_setprio level of the product phases of f_backward_coop (H <= 64); 0 switches it off
 #endif
+#ifndef GPE_FCOOP_SWP
+#define GPE_FCOOP_SWP 0      // f_forward_coop<128>: B fragments of K tile kt+1 requested before the products of tile kt
+#endif
 #ifndef GPE_PIPE_G0REG
 #define GPE_PIPE_G0REG 0     // f_backward_pipe: layer-0 gradient sums per lane in registers (1) or reduced per tile (0: 12 registers fewer)
 #endif
@@ -838,6 +841,31 @@ __global__ __launch_bounds__(H * 4, 2) void f_forward_coop(NetDesc nd, const flo
             acc[0] = *reinterpret_cast<const f32x4*>(&w0s[(4 + (j - 1)) * H + 16 * w + 4 * q]);      // b_j
 #pragma unroll
             for (int c = 1; c < C; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (H == 128 && GPE_FCOOP_SWP) {
+                // one K tile of lookahead on the B fragments.  The eight waves run this loop in lockstep behind the layer's barrier, and the
+                // compiler -- short of registers beside the 128-160 weight registers -- requests a K tile's fragments only when the previous
+                // tile's last product has issued and waits for them two products later: both waves of a SIMD then sit in the same LDS round
+                // trip, sixteen times per layer (tools/loop_dump.py).  Requested one K tile ahead, a round trip hides behind 16 products.
+                f32x4 bfn[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) bfn[c] = *reinterpret_cast<const f32x4*>(&buf[(c * NT + 0) * 256 + lane * 4]);
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) {
+                    f32x4 bf[C];
+#pragma unroll
+                    for (int c = 0; c < C; ++c) bf[c] = bfn[c];
+                    if (kt + 1 < NT) {
+#pragma unroll
+                        for (int c = 0; c < C; ++c) bfn[c] = *reinterpret_cast<const f32x4*>(&buf[(c * NT + kt + 1) * 256 + lane * 4]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                        for (int c = 0; c < C; ++c)
+                            acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j - 1][kt][s2], bf[c][s2], acc[c], 0, 0, 0);
+                }
+            } else
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt) {
                 if constexpr (H == 128 && GPE_FCOOP_ALT_PRIO) {   // SIMD partners (w, w + 4) take turns at the matrix pipe, one K tile each
