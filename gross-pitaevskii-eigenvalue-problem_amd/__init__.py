@@ -15,8 +15,9 @@ from .engine import Engine, GPEConfig, GPEError
 from . import dp, surface, checkpoint, relobralo
 from .surface import refine, refine_negative, notebook, box, gravity_well, box_to_gaussian
 from .surface import vary_beta_harmonic, vary_beta_gravity_well, vary_beta_box_and_gaussian
+from .surface import pinn2d, pinn2d_minimal          # src/gross_pitaevskii_2D.py, src/gross_pitaevskii_2D_minimal.py
 
 vary_beta = vary_beta_harmonic      # refine/vary_potential_parameter_harmonic.py, the flavour SURVEY 8(f3) cites
 
 __all__ = ["capi", "Engine", "GPEConfig", "GPEError", "dp", "surface", "checkpoint", "refine", "refine_negative", "notebook", "box", "gravity_well", "box_to_gaussian",
-           "vary_beta", "vary_beta_harmonic", "vary_beta_gravity_well", "vary_beta_box_and_gaussian"]
+           "vary_beta", "vary_beta_harmonic", "vary_beta_gravity_well", "vary_beta_box_and_gaussian", "pinn2d", "pinn2d_minimal"]

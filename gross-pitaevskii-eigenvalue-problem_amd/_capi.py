@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-GPE_ABI_VERSION = 1
+GPE_ABI_VERSION = 2
 GPE_MAX_LAYERS = 12
 GPE_MAX_ORTH = 4
 GPE_MAX_DIM = 3
@@ -26,6 +26,7 @@ BASE_HERMITE, BASE_BOX, BASE_PRECOMPUTED = 0, 1, 2
 ENV_NONE, ENV_SIN = 0, 1
 RIESZ_PAPER, RIESZ_SUM, RIESZ_VARIATIONAL = 0, 1, 2
 NET_MLP, NET_RESIDUAL = 0, 1
+LAMBDA_RAYLEIGH, LAMBDA_ENERGY = 0, 1
 
 
 class gpe_config(C.Structure):
@@ -44,14 +45,15 @@ class gpe_config(C.Structure):
         ("path", C.c_int32), ("world_size", C.c_int32), ("history_capacity", C.c_int32),
         ("stop_tol", C.c_float), ("stop_patience", C.c_int32),
         ("base_kind", C.c_int32), ("envelope", C.c_int32), ("box_L", C.c_float), ("env_L", C.c_float),
-        ("w_riesz", C.c_float), ("riesz_kind", C.c_int32), ("net_kind", C.c_int32), ("reserved_cfg", C.c_int32),
+        ("w_riesz", C.c_float), ("riesz_kind", C.c_int32), ("net_kind", C.c_int32), ("lambda_kind", C.c_int32),
+        ("w_reg_f", C.c_float), ("reg_f_eps", C.c_float), ("w_reg_lam", C.c_float), ("reg_lam_eps", C.c_float),
     ]
 
 
 class gpe_scalars(C.Structure):
     _fields_ = [(n, C.c_double) for n in
                 ("loss", "pde", "bc", "norm", "sym", "orth", "mu", "num", "den", "sum_r2", "integral",
-                 "grad_norm", "lr", "step", "nonfinite", "riesz")]
+                 "grad_norm", "lr", "step", "nonfinite", "riesz", "reg")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -38,6 +38,8 @@ struct Phys {
     double n_global;                 // N of the means
     float inv_world;                 // 1/world_size: scales the replicated boundary batch
     int n_orth;
+    int lambda_kind;                 // GPE_LAMBDA_*
+    float w_reg_f, reg_f_eps, w_reg_lam, reg_lam_eps;
 };
 
 // Indices into the double "sums" exchange buffer (all-reduced over ranks between phase 1 and 2).
@@ -178,6 +180,27 @@ GPE_DEV void riesz_coefs(const Phys& ph, float& ak, float& ap, float& ai, bool& 
     if (ph.riesz_kind == GPE_RIESZ_SUM) { ak = 0.5f; ap = 0.5f; ai = gi; normalised = false; }
     else if (ph.riesz_kind == GPE_RIESZ_VARIATIONAL) { ak = ph.kin; ap = 1.0f; ai = 2.0f * gi; normalised = true; }
     else { ak = 0.5f; ap = 1.0f; ai = gi; normalised = true; }
+}
+
+// The head kernel files the three energy sums with the Riesz coefficients on them; the energy-functional eigenvalue estimate
+// (GPE_LAMBDA_ENERGY: src/gross_pitaevskii_2D.py:192) is their c / 1 / gamma combination over sum u^2.  gamma sum |u|^(p+1) is
+// (p+1)/k times the interaction sum for ai = k gamma / (p+1), so gamma = 0 needs no division.
+GPE_DEV bool phys_needs_energy_sums(const Phys& ph) { return ph.w_riesz != 0.f || ph.lambda_kind == GPE_LAMBDA_ENERGY; }
+GPE_DEV double energy_numerator(const Phys& ph, const double* sums) {
+    float ak, ap, ai; bool nrm;
+    riesz_coefs(ph, ak, ap, ai, nrm);
+    const double ci = ph.riesz_kind == GPE_RIESZ_VARIATIONAL ? 0.5 * (double)(ph.p + 1) : (double)(ph.p + 1);
+    return (double)ph.kin * sums[S_RZ_K] / (double)ak + sums[S_RZ_P] / (double)ap + ci * sums[S_RZ_I];
+}
+GPE_DEV double lambda_of(const Phys& ph, const double* sums, double num, double den) {
+    return ph.lambda_kind == GPE_LAMBDA_ENERGY ? energy_numerator(ph, sums) / den : num / den;
+}
+// w_reg_f / (mean u^2 + eps_f) + w_reg_lam / (lambda^2 + eps_l)    (src/gross_pitaevskii_2D.py:197-211)
+GPE_DEV double reg_terms(const Phys& ph, double den, double lam) {
+    double r = 0.0;
+    if (ph.w_reg_f != 0.f) r += (double)ph.w_reg_f / (den / ph.n_global + (double)ph.reg_f_eps);
+    if (ph.w_reg_lam != 0.f) r += (double)ph.w_reg_lam / (lam * lam + (double)ph.reg_lam_eps);
+    return r;
 }
 
 GPE_DEV float ipowf(float u, int p) {

@@ -192,7 +192,7 @@ GPE_DEV void update_core(int P, float* __restrict__ theta, float* __restrict__ a
         else { for (int i = 0; i < 16; ++i) tot += red[i]; }
         double gn = sqrt(tot);
         double num = p_num, den = p_den;
-        double lam = (double)(float)(num / den);
+        double lam = (double)(float)lambda_of(ph, sums, num, den);
         double I = (double)((float)den * ph.dx);
         double sr2 = (double)p_sr2;
         double pde = sr2 / ph.n_global;
@@ -202,15 +202,16 @@ GPE_DEV void update_core(int P, float* __restrict__ theta, float* __restrict__ a
         double orth = 0.0;
         for (int j = 0; j < ph.n_orth; ++j) { double oj = sums[S_ORTH0 + j] * ph.dx; orth += oj * oj; }
         double riesz = 0.0;
-        if (ph.w_riesz != 0.f) {
+        if (ph.w_riesz != 0.f) {          // (the sums are also filed for the energy-functional lambda; the TERM only with its weight)
             const double fI = ph.riesz_kind == GPE_RIESZ_VARIATIONAL ? pow(I, -0.5 * (double)(ph.p - 1)) : 1.0;
             const double Lrot = ph.complex_psi ? (double)ph.omega_rot * sums[S_RZ_L] : 0.0;      // rotating frame: - Omega <L_z>
             riesz = (sums[S_RZ_K] + sums[S_RZ_P] + fI * sums[S_RZ_I] - Lrot) / (ph.riesz_kind == GPE_RIESZ_SUM ? 1.0 : den);
         }
-        double loss = ph.w_pde * pde + ph.w_bc * bc + ph.w_norm * nrm + ph.w_sym * sym + ph.w_orth * orth + ph.w_riesz * riesz;
+        double reg = reg_terms(ph, den, lam);
+        double loss = ph.w_pde * pde + ph.w_bc * bc + ph.w_norm * nrm + ph.w_sym * sym + ph.w_orth * orth + ph.w_riesz * riesz + reg;
         if (mse_mode) {           // pre-training: loss = mean((NN - target)^2); plain Adam (no clip, no scheduler, no early stop)
             loss = (double)grad_load<SC1>(&grad[P + GT_MSE_SE2]) / (ph.n_global * ph.n_out);
-            lam = 0.0; pde = 0.0; nrm = 0.0; bc = 0.0; sym = 0.0; orth = 0.0; riesz = 0.0;
+            lam = 0.0; pde = 0.0; nrm = 0.0; bc = 0.0; sym = 0.0; orth = 0.0; riesz = 0.0; reg = 0.0;
         }
         int skip = !(isfinite(loss) && isfinite(gn));
         const int frozen = do_update && p_stopped;
@@ -230,7 +231,7 @@ GPE_DEV void update_core(int P, float* __restrict__ theta, float* __restrict__ a
         gpe_scalars r;
         r.loss = loss; r.pde = pde; r.bc = bc; r.norm = nrm; r.sym = sym; r.orth = orth; r.mu = lam;
         r.num = num; r.den = den; r.sum_r2 = sr2; r.integral = I; r.grad_norm = gn; r.lr = lr;
-        r.step = (double)step; r.nonfinite = skip ? 1.0 : 0.0; r.riesz = riesz;
+        r.step = (double)step; r.nonfinite = skip ? 1.0 : 0.0; r.riesz = riesz; r.reg = reg;
         s_rec = r; s_step = step; s_frozen = frozen; s_book = 1;
     }
     __syncthreads();
@@ -703,12 +704,16 @@ static bool fwd_coop(gpe_engine* e, const Batch& b) {
 }
 #define HEAD_SLOTS 512
 static bool seed_in_reverse(gpe_engine* e);
+// no Riesz term, Rayleigh-quotient eigenvalue, no regularisers: the loss the fused head / seed code paths implement
+static bool plain_terms(const gpe_engine* e) {
+    return e->cfg.w_riesz == 0.f && e->cfg.lambda_kind == GPE_LAMBDA_RAYLEIGH && e->cfg.w_reg_f == 0.f && e->cfg.w_reg_lam == 0.f;
+}
 // whole steps (gpe_step / gpe_run) of the small-batch class whose reverse kernel forms the seeds: the cooperative forward kernel runs
 // the head too, k_head_pde is not launched and the step sums are added in a fixed order
 // problem class whose head the forward kernels can run (head_point_real): real psi, no orthogonality / Riesz / symmetry terms
 static bool head_class(gpe_engine* e) {
     return e->fuse_head && e->head_slots && e->path == GPE_PATH_FUSED && !e->wide && e->H <= 64 && e->nd.n_out == 1 && !e->cfg.complex_psi &&
-           e->ph.n_orth == 0 && e->cfg.w_riesz == 0.f && e->cfg.w_sym == 0.f && e->main.C >= 3 && e->main.n > 0;
+           e->ph.n_orth == 0 && plain_terms(e) && e->cfg.w_sym == 0.f && e->main.C >= 3 && e->main.n > 0;
 }
 // ... by the cooperative forward kernel (small batches; the reverse kernel forms the seeds and adds the triples)
 static bool head_fusable_coop(gpe_engine* e) {
@@ -831,7 +836,7 @@ static bool use_pipe(gpe_engine* e, int C);
 // the kernel forms the seeds itself and k_seed_pde is not launched
 static bool seed_in_reverse(gpe_engine* e) {
     return e->fuse_seed && e->path == GPE_PATH_FUSED && !e->wide && e->nd.n_out == 1 && !e->cfg.complex_psi && e->ph.n_orth == 0 &&
-           e->cfg.w_riesz == 0.f && e->cfg.w_sym == 0.f && e->main.C >= 3 && e->main.n > 0 && e->n_pde <= e->fuse_seed_max &&
+           plain_terms(e) && e->cfg.w_sym == 0.f && e->main.C >= 3 && e->main.n > 0 && e->n_pde <= e->fuse_seed_max &&
            use_pipe(e, e->main.C) && bwd_kind(e, e->main) == 3;
 }
 static int bwd_kind(gpe_engine* e, const Batch& b) {
@@ -1267,6 +1272,7 @@ static void fill_phys(gpe_engine* e) {
     p.perturb_scale = c.perturb_scale; p.bc_nn_scale = c.bc_nn_scale;
     p.w_pde = c.w_pde; p.w_bc = c.w_bc; p.w_norm = c.w_norm; p.w_sym = c.w_sym; p.w_orth = c.w_orth;
     p.sym_sign = c.sym_sign; p.dx = c.dx; p.w_riesz = c.w_riesz; p.riesz_kind = c.riesz_kind;
+    p.lambda_kind = c.lambda_kind; p.w_reg_f = c.w_reg_f; p.reg_f_eps = c.reg_f_eps; p.w_reg_lam = c.w_reg_lam; p.reg_lam_eps = c.reg_lam_eps;
     p.n_global = (double)(c.n_global > 0 ? c.n_global : (e->n_pde > 0 ? e->n_pde : 1));
     p.inv_world = 1.0f / (float)(c.world_size > 0 ? c.world_size : 1);
     int no = 0;
@@ -1394,6 +1400,12 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
     if (c.w_riesz != 0.f && no != 1 && !(c.complex_psi && no == 2 && c.p == 3))
         CFAIL("the Riesz energy term needs real psi (out=1) or complex psi (out=2) with p = 3");
     if (c.riesz_kind < 0 || c.riesz_kind > GPE_RIESZ_VARIATIONAL) CFAIL("Unknown Riesz kind: %d", c.riesz_kind);
+    if (c.lambda_kind != GPE_LAMBDA_RAYLEIGH && c.lambda_kind != GPE_LAMBDA_ENERGY) CFAIL("Unknown lambda kind: %d", c.lambda_kind);
+    if (c.lambda_kind == GPE_LAMBDA_ENERGY && (c.complex_psi || no != 1 || (c.p & 1) == 0))
+        CFAIL("the energy-functional lambda needs real psi (out=1) and an odd power p");
+    if (c.w_reg_lam != 0.f && c.lambda_kind != GPE_LAMBDA_ENERGY) CFAIL("the 1/lambda^2 regulariser needs the energy-functional lambda");
+    if ((c.w_reg_f != 0.f || c.w_reg_lam != 0.f) && (c.complex_psi || no != 1)) CFAIL("the regularisers need real psi (out=1)");
+    if ((c.w_reg_f != 0.f && !(c.reg_f_eps > 0.f)) || (c.w_reg_lam != 0.f && !(c.reg_lam_eps > 0.f))) CFAIL("regulariser eps must be > 0");
     for (int i = 1; i < c.n_layers - 1; ++i)
         if (c.layers[i] < 1 || c.layers[i] > 1024) CFAIL("hidden width %d out of range", c.layers[i]);
     NetDesc& nd = e->nd;

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(1024) void k_head_pde(Phys ph, float base_norm, Pts
         }
         for (int j = 0; j < ph.n_orth; ++j) so[j] += (double)(orth[j][m] * U[0][0]);
         if constexpr (D >= 1) {
-            if (ph.w_riesz != 0.f) {            // Paper nb c6:L163-174 ; src/gross_pitaevskii_2D.py:112-151
+            if (phys_needs_energy_sums(ph)) {   // Paper nb c6:L163-174 ; src/gross_pitaevskii_2D.py:112-151 ; the energy-functional lambda (:192)
                 float ak, ap, ai; bool nrm;
                 riesz_coefs(ph, ak, ap, ai, nrm);
                 float g2 = 0.f, rho = 0.f;
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(1024) void k_head_pde(Phys ph, float base_norm, Pts
             }
         }
     }
-    if (ph.w_riesz != 0.f) {
+    if (phys_needs_energy_sums(ph)) {
         double t;
         t = block_sum_256(rzk, red); if (threadIdx.x == 0) atomicAdd(&sums[S_RZ_K], t);
         t = block_sum_256(rzp, red); if (threadIdx.x == 0) atomicAdd(&sums[S_RZ_P], t);
@@ -281,8 +281,20 @@ __global__ __launch_bounds__(1024) void k_seed_pde(Phys ph, Pts x, const float* 
             if (tot[2] != 0.0) atomicAdd(&lsums_out[LS_BC_SE2], tot[2]);
         }
     } else { num = sums[S_NUM]; den = sums[S_DEN]; }
+    // energy-functional lambda (src/gross_pitaevskii_2D.py:192) and the regularisers (:197-211): lambda is NOT the Rayleigh quotient of the
+    // residual's operator on these points, so d loss / d lambda = -2 w_pde / N sum r u + d L_lambda / d lambda does not vanish (SURVEY quirk
+    // Q10) and is carried to u and to grad u through d lambda / d u.  sum r u = num_R - lambda den: both sums are already global.
+    const float lam_all = (float)lambda_of(ph, sums, num, den);
+    float lam_bar = 0.f, regf_bar = 0.f;
+    if (ph.lambda_kind == GPE_LAMBDA_ENERGY) {
+        const double l = (double)lam_all;
+        double lb = -2.0 * (double)ph.w_pde / ph.n_global * (num - l * den);
+        if (ph.w_reg_lam != 0.f) { const double q = l * l + (double)ph.reg_lam_eps; lb += -2.0 * (double)ph.w_reg_lam * l / (q * q); }
+        lam_bar = (float)(lb / den);                      // (the 1/den of d lambda / d u is folded in)
+    }
+    if (ph.w_reg_f != 0.f) { const double q = den / ph.n_global + (double)ph.reg_f_eps; regf_bar = (float)(-2.0 * (double)ph.w_reg_f / (q * q * ph.n_global)); }
     for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < N; m += (int64_t)gridDim.x * blockDim.x) {
-        float lam = (float)(num / den);
+        float lam = lam_all;
         float I = (float)den * ph.dx;
         float xv[3] = {0.f, 0.f, 0.f};
         for (int k = 0; k < ph.dim; ++k) xv[k] = pts_at(x, m, ph.dim, k);
@@ -351,6 +363,16 @@ __global__ __launch_bounds__(1024) void k_seed_pde(Phys ph, Pts x, const float* 
                                 Ub[2] += wq * (-Om) * sgn * (-xv[0] * u[q]);    // d<L_z>/d(d_y psi_r) = -x psi_i ; /d(d_y psi_i) = x psi_r
                             }
                         }
+                    }
+                }
+                if constexpr (D >= 1) {
+                    if (lam_bar != 0.f || regf_bar != 0.f) {       // real psi, out = 1 (checked at gpe_create)
+                        const float uu = u[0];
+                        const float sg = uu < 0.f ? -1.f : 1.f;
+                        // den * d lambda / d u = 2 V u + gamma (p+1) |u|^p sgn u - 2 lambda u ;  den * d lambda / d u_k = 2 c u_k
+                        Ub[0] += lam_bar * (2.f * V * uu + ph.gamma * (float)(ph.p + 1) * sg * ipowf(fabsf(uu), ph.p) - 2.f * lam * uu) + regf_bar * uu;
+#pragma unroll
+                        for (int k = 0; k < D; ++k) Ub[1 + k] += lam_bar * 2.f * ph.kin * ux_in[(int64_t)k * ld + m];
                     }
                 }
                 if (ph.complex_psi && ph.omega_rot != 0.f && D >= 2) {

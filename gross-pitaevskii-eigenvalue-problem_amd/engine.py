@@ -76,6 +76,11 @@ class GPEConfig:
     w_riesz: float = 0.0
     riesz_kind: int = capi.RIESZ_PAPER
     net_kind: int = capi.NET_MLP
+    lambda_kind: int = capi.LAMBDA_RAYLEIGH      # LAMBDA_ENERGY: src/gross_pitaevskii_2D.py:192
+    w_reg_f: float = 0.0                         # w / (mean u^2 + reg_f_eps)        src/gross_pitaevskii_2D.py:201
+    reg_f_eps: float = 1e-2
+    w_reg_lam: float = 0.0                       # w / (lambda^2 + reg_lam_eps)      src/gross_pitaevskii_2D.py:204
+    reg_lam_eps: float = 1e-6
 
     def to_c(self) -> capi.gpe_config:
         c = capi.gpe_config()
@@ -90,14 +95,14 @@ class GPEConfig:
         for i in range(3):
             c.omega[i] = float(om[i])
         for name in ("activation", "potential", "p", "base_mode", "base_deriv", "sched", "patience", "path",
-                     "world_size", "history_capacity", "n_global", "stop_patience", "base_kind", "envelope", "riesz_kind", "net_kind"):
+                     "world_size", "history_capacity", "n_global", "stop_patience", "base_kind", "envelope", "riesz_kind", "net_kind", "lambda_kind"):
             setattr(c, name, int(getattr(self, name)))
         c.complex_psi = int(bool(self.complex_psi))
         c.abs_power = int(bool(self.abs_power))
         for name in ("kinetic_coeff", "pot_scale", "pot_a", "pot_v0", "pot_k", "omega_rot", "gamma", "perturb_scale",
                      "bc_nn_scale", "w_pde", "w_bc", "w_norm", "w_sym", "w_orth", "sym_sign", "dx", "lr", "beta1",
                      "beta2", "eps", "clip_norm", "T_0", "T_mult", "eta_min", "factor", "min_lr", "threshold",
-                     "stop_tol", "box_L", "env_L", "w_riesz"):
+                     "stop_tol", "box_L", "env_L", "w_riesz", "w_reg_f", "reg_f_eps", "w_reg_lam", "reg_lam_eps"):
             setattr(c, name, float(getattr(self, name)))
         return c
 

@@ -968,3 +968,167 @@ refine = types.SimpleNamespace(GrossPitaevskiiPINN=_RefinePINN, train_gpe_model=
 notebook = types.SimpleNamespace(GrossPitaevskiiPINN=_NotebookPINN, train_gpe_model=_nb_train,
                                  advanced_initialization=_nb_advanced_initialization, density=_nb_density,
                                  KIND="xavier_uniform")
+
+
+# ================================================================================================
+# 2D classes: src/gross_pitaevskii_2D.py (class :16-274) and src/gross_pitaevskii_2D_minimal.py (class :12-222, train_pinn :278-327)
+# ================================================================================================
+_PINN2D_FLAVOR = _Flavor("pinn2d", capi.ACT_TANH, 1.0, 1.0, 0, 0.0, "xavier_uniform")
+
+
+class _PINN2D(_PINNBase):
+    """GrossPitaevskiiPINN(layers, hbar, m, g) of the two 2D scripts: -lap u + V u + g |u|^2 u = lambda u on the disk around (pi/2, pi/2),
+    Gaussian potential, plain tanh network, no analytic base.  Their loss (src/gross_pitaevskii_2D.py:215-242):
+        10 mean(u(x_bc)^2)  +  1/2 (sum |grad u|^2 + sum V u^2 + g/2 sum u^4)  +  mean(r^2) + 1/(mean u^2 + 1e-2) + 1/(lambda^2 + 1e-6),
+        lambda = mean(|grad u|^2 + V u^2 + g u^4) / mean(u^2),   r = -lap u + V u + g |u^2| u - lambda u.
+    Quirk Q1: the reference multiplies V [N] by u [N,1], so for N > 1 its lambda and residual are [N,N] broadcasts; this class
+    evaluates the per-point formulas above, which is what the reference computes when called with one point (the golden vectors)."""
+    _flavor = _PINN2D_FLAVOR
+
+    def __init__(self, layers, hbar=1.0, m=1.0, g=100.0):
+        super().__init__(layers, hbar, m, mode=0, gamma=g)
+        self.use_perturbation = False
+
+    @property
+    def g(self):
+        return self.gamma
+
+    @g.setter
+    def g(self, v):
+        self.gamma = v
+        if self._engine is not None:
+            self._engine.set_gamma(float(v))
+
+    _W_FULL = (1.0, 10.0, 0.0, 0.0, 0.0, 1.0)         # w_pde, w_bc (boundary_loss's own x 10), w_norm, w_sym, w_orth, w_riesz
+
+    def _extra_config(self):
+        return dict(potential=capi.POT_PRECOMPUTED, p=3, abs_power=True, w_pde=1.0, w_bc=10.0, w_norm=0.0, w_riesz=1.0,
+                    riesz_kind=capi.RIESZ_SUM, lambda_kind=capi.LAMBDA_ENERGY, w_reg_f=1.0, reg_f_eps=1e-2, w_reg_lam=1.0,
+                    reg_lam_eps=1e-6, clip_norm=0.0, lr=1e-3, dx=1.0)
+
+    def compute_potential(self, inputs, V0=1.0, x0=np.pi / 2, y0=np.pi / 2, sigma=0.5):
+        """V0 exp(-((x - x0)^2 + (y - y0)^2) / (2 sigma^2))   (src/gross_pitaevskii_2D.py:244-274) -> [N]"""
+        x, y = inputs[:, 0], inputs[:, 1]
+        return V0 * torch.exp(-((x - x0) ** 2 + (y - y0) ** 2) / (2 * sigma ** 2))
+
+    def _bind(self, eng, inputs, boundary=None):
+        x = eng._to_dev(inputs.detach() if isinstance(inputs, torch.Tensor) else inputs, "x")
+        eng.bind_points(x, self.compute_potential(x))
+        eng.bind_boundary(boundary)
+        return x
+
+    def _terms(self, inputs, predictions=None, boundary=None, want_fields=False):
+        eng = self._get_engine()
+        eng.set_gamma(float(self.gamma))
+        eng.set_loss_weights(*(self._W_FULL if boundary is not None else (1.0, 0.0, 0.0, 0.0, 0.0, 1.0)))
+        eng.set_perturb_scale(1.0 if predictions is None else self._scale_of(inputs, predictions))
+        self._bind(eng, inputs, boundary)
+        out = eng.residual(want_fields=want_fields)
+        eng.set_loss_weights(*self._W_FULL)
+        return out
+
+    def pde_loss(self, inputs, predictions):
+        """-> (mean(r^2) + L_f + L_lambda, r [N,1], lambda)   (src/gross_pitaevskii_2D.py:154-213)"""
+        sc, _, res = self._terms(inputs, predictions, want_fields=True)
+        dev = _device()
+        return (torch.tensor(sc["pde"] + sc["reg"], dtype=torch.float32, device=dev), res,
+                torch.tensor(sc["mu"], dtype=torch.float32, device=dev))
+
+    def riesz_loss(self, predictions, inputs):
+        """1/2 (sum |grad u|^2 + sum V u^2 + g/2 sum u^4)   (src/gross_pitaevskii_2D.py:112-151)"""
+        sc, _, _ = self._terms(inputs, predictions)
+        return torch.tensor(sc["riesz"], dtype=torch.float32, device=_device())
+
+    def boundary_loss(self, x_bc, y_bc):
+        """10 mean(u(x_bc)^2): the reference replaces y_bc by zeros (src/gross_pitaevskii_2D.py:83-109)"""
+        eng = self._get_engine()
+        eng.set_loss_weights(*self._W_FULL)
+        return 10.0 * super().boundary_loss(x_bc, None)
+
+    def loss(self, x, x_bc, u_bc):
+        """boundary_loss + pde_loss + riesz_loss, weights 1 (src/gross_pitaevskii_2D.py:215-242)"""
+        sc, _, _ = self._terms(x, None, boundary=x_bc)
+        return torch.tensor(sc["loss"], dtype=torch.float32, device=_device())
+
+    total_loss = loss                                  # the name in src/gross_pitaevskii_2D_minimal.py:201-222
+
+
+def _pinn2d_initialize_weights(m):
+    """initialize_weights (src/gross_pitaevskii_2D.py:614-618): Xavier-uniform weights, bias 0.01, from torch's CPU RNG in module order."""
+    m._flat = _advanced_init(m.layers, 0, "xavier_uniform", m._spec())
+    if m._engine is not None:
+        m._engine.set_params(m._flat)
+
+
+def _pinn2d_boundary(N_u, center, radius):
+    theta = np.linspace(0, 2 * np.pi, N_u)
+    X_u = np.column_stack((center[0] + radius * np.cos(theta), center[1] + radius * np.sin(theta)))
+    return X_u, np.zeros((X_u.shape[0], 1))
+
+
+def _pinn2d_prepare_polar(N_u, N_f, center=(np.pi / 2, np.pi / 2), radius=np.pi / 2):
+    """prepare_training_data of src/gross_pitaevskii_2D.py:277-295: N_u points on the circle; N_f collocation points drawn as (angle,
+    radius) pairs from numpy's global generator -- the reference draws them one pair at a time, this draws the same stream as one block."""
+    X_u, u = _pinn2d_boundary(N_u, center, radius)
+    r = np.random.random_sample((N_f, 2))
+    ang, rad = 0.0 + (2 * np.pi - 0.0) * r[:, 0], 0.0 + (radius - 0.0) * r[:, 1]
+    X_f = np.column_stack((center[0] + rad * np.cos(ang), center[1] + rad * np.sin(ang)))
+    return X_f, X_u, u
+
+
+def _pinn2d_prepare_square(N_u, N_f, center=(np.pi / 2, np.pi / 2), radius=np.pi / 2):
+    """prepare_training_data of src/gross_pitaevskii_2D_minimal.py:225-261: uniform draws in the bounding square, kept inside the disk
+    (so fewer than N_f points come back)."""
+    X_u, u = _pinn2d_boundary(N_u, center, radius)
+    cx = np.random.uniform(center[0] - radius, center[0] + radius, N_f)
+    cy = np.random.uniform(center[1] - radius, center[1] + radius, N_f)
+    keep = (cx - center[0]) ** 2 + (cy - center[1]) ** 2 <= radius ** 2
+    return np.column_stack((cx[keep], cy[keep])), X_u, u
+
+
+def _pinn2d_solution_on_grid(model, num_grid_pts=100, center=(np.pi / 2, np.pi / 2), radius=np.pi / 2):
+    """numerical part of plot_solution (src/gross_pitaevskii_2D_minimal.py:330-371): the prediction on the plotting grid -> X, Y, u [n,n]"""
+    xv = np.linspace(center[0] - radius, center[0] + radius, num_grid_pts)
+    yv = np.linspace(center[1] - radius, center[1] + radius, num_grid_pts)
+    X, Y = np.meshgrid(xv, yv)
+    pts = np.hstack((X.flatten()[:, None], Y.flatten()[:, None])).astype(np.float32)
+    u = model.forward(torch.as_tensor(pts, device=_device())).cpu().numpy().reshape(num_grid_pts, num_grid_pts)
+    return X, Y, u
+
+
+def _pinn2d_train(N_u=500, N_f=10000, layers=[2, 400, 400, 400, 1], epochs=1000, g=100.0, verbose=True, chunk=400, data=None,
+                  prepare=_pinn2d_prepare_square):
+    """train_pinn of src/gross_pitaevskii_2D_minimal.py:278-327: model + initialize_weights + Adam(lr 1e-3), prepare_training_data,
+    `epochs` full-batch steps on total_loss, a progress line every 400 epochs (the reference also draws a figure there: plot_solution's
+    numbers are solution_on_grid).  Extras: `g` (the reference builds the class with its default 100), `data` = (X_f, X_u, u) to skip
+    the random draw.  Returns the model; model.history holds every epoch's record (loss, mu, pde, bc, riesz, reg, ...)."""
+    model = _PINN2D(layers, g=g)
+    model.apply(_pinn2d_initialize_weights)
+    X_f, X_u, u_train = data if data is not None else prepare(N_u, N_f)
+    dev = _device()
+    model.start_flat = model._flat.copy()
+    eng = model._get_engine(history_capacity=max(int(epochs), 1))
+    eng.set_loss_weights(*model._W_FULL)
+    model._bind(eng, torch.as_tensor(np.asarray(X_f, dtype=np.float32), device=dev),
+                torch.as_tensor(np.asarray(X_u, dtype=np.float32), device=dev))
+    done = 0
+    while done < epochs:
+        n = min(chunk, epochs - done)
+        eng.run(n)
+        done += n
+    hist = _history(eng, 1, epochs) if epochs > 0 else []
+    if verbose:
+        for i, h in enumerate(hist):
+            if i % 400 == 0:
+                print(f"Epoch [{i}/{epochs}], Loss: {h['loss']:.6f}")
+    model._pull()
+    model.history = _History(hist)
+    return model
+
+
+pinn2d = types.SimpleNamespace(GrossPitaevskiiPINN=_PINN2D, prepare_training_data=_pinn2d_prepare_polar, initialize_weights=_pinn2d_initialize_weights,
+                               train_pinn=lambda *a, **k: _pinn2d_train(*a, **dict(dict(prepare=_pinn2d_prepare_polar), **k)),
+                               solution_on_grid=_pinn2d_solution_on_grid)
+pinn2d_minimal = types.SimpleNamespace(GrossPitaevskiiPINN=_PINN2D, prepare_training_data=_pinn2d_prepare_square,
+                                       initialize_weights=_pinn2d_initialize_weights, train_pinn=_pinn2d_train,
+                                       solution_on_grid=_pinn2d_solution_on_grid)

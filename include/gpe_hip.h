@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GPE_ABI_VERSION 1
+#define GPE_ABI_VERSION 2
 #define GPE_MAX_LAYERS 12 /* entries of layers[]: [d, H_1, ..., H_L, out] */
 #define GPE_MAX_ORTH 4
 #define GPE_MAX_DIM 3
@@ -60,6 +60,11 @@ enum { GPE_BASE_HERMITE = 0, GPE_BASE_BOX = 1, GPE_BASE_PRECOMPUTED = 2 };
 enum { GPE_ENV_NONE = 0, GPE_ENV_SIN = 1 };
 enum { GPE_RIESZ_PAPER = 0, GPE_RIESZ_SUM = 1, GPE_RIESZ_VARIATIONAL = 2 };
 enum { GPE_NET_MLP = 0, GPE_NET_RESIDUAL = 1 };
+/* eigenvalue estimate inside the residual:  RAYLEIGH  lambda = sum u (H u) / sum u^2  (refine/harmonic_pinn_simulation.py:186-188; its
+ * branch of the gradient vanishes identically);  ENERGY  lambda = [c sum |grad u|^2 + sum V u^2 + gamma sum |u|^(p+1)] / sum u^2,
+ * the energy-functional form of the 2D classes (src/gross_pitaevskii_2D.py:192, src/gross_pitaevskii_2D_minimal.py:179; per-point
+ * reading of quirk Q1), whose branch of the gradient does NOT vanish and is carried through the reverse pass */
+enum { GPE_LAMBDA_RAYLEIGH = 0, GPE_LAMBDA_ENERGY = 1 };
 
 typedef struct gpe_engine gpe_engine; /* opaque */
 
@@ -125,7 +130,12 @@ typedef struct gpe_config {
      * residual blocks  tanh(lin2(tanh(lin1 x)) + x)  and Linear(H,out) (refine/box_to_gaussian_pinn_simulation.py:52-63,100-130);
      * parameters in state_dict order network.0, network.2.lin1, network.2.lin2, network.3.lin1, ... (generic kernel set) */
     int32_t net_kind;
-    int32_t reserved_cfg;
+    int32_t lambda_kind;          /* GPE_LAMBDA_* (ENERGY: real psi, odd p) */
+    /* regularisers of the 2D classes' pde_loss (src/gross_pitaevskii_2D.py:197-211 ; arXiv 2010.05075), added to the total loss:
+     *   w_reg_f   / (mean(u^2) + reg_f_eps)      "L_f": keeps the network off the trivial eigenfunction (reference: w = 1, eps = 1e-2)
+     *   w_reg_lam / (lambda^2 + reg_lam_eps)     "L_lambda": keeps lambda off zero (reference: w = 1, eps = 1e-6; needs GPE_LAMBDA_ENERGY)
+     * mean over n_global; both zero: the terms are not formed */
+    float w_reg_f, reg_f_eps, w_reg_lam, reg_lam_eps;
 } gpe_config;
 
 /* Per-step scalars (refine/...:364-381 keeps loss every 10 and lambda every 100 epochs). */
@@ -137,6 +147,7 @@ typedef struct gpe_scalars {
     double step;                  /* 1-based optimiser step that produced this record */
     double nonfinite;             /* 1 when the loss or gradient was not finite (no update) */
     double riesz;                 /* Riesz energy E (0 when w_riesz == 0) */
+    double reg;                   /* w_reg_f / (mean u^2 + eps) + w_reg_lam / (lambda^2 + eps)  (0 when both weights are 0) */
 } gpe_scalars;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */

@@ -44,6 +44,7 @@ SCHED_CONST, SCHED_COSINE_LOSS, SCHED_PLATEAU = 0, 1, 2
 BASE_HERMITE, BASE_BOX, BASE_PRECOMPUTED = 0, 1, 2
 ENV_NONE, ENV_SIN = 0, 1
 RIESZ_PAPER, RIESZ_SUM, RIESZ_VARIATIONAL = 0, 1, 2
+LAMBDA_RAYLEIGH, LAMBDA_ENERGY = 0, 1      # eigenvalue estimate inside the residual: sum u Hu / sum u^2 | src/gross_pitaevskii_2D.py:192
 NET_MLP, NET_RESIDUAL = 0, 1
 
 
@@ -81,6 +82,11 @@ class Problem:
     env_L: float = 1.0
     net_kind: int = NET_MLP                    # NET_RESIDUAL: refine/box_to_gaussian_pinn_simulation.py:52-63,100-130 (layers = [d, H, ..., H, out],
                                                #   len(layers) - 3 residual blocks tanh(lin2(tanh(lin1 x)) + x) behind Linear(d,H) + activation)
+    lambda_kind: int = LAMBDA_RAYLEIGH         # LAMBDA_ENERGY: lambda = [c sum |grad u|^2 + sum V u^2 + gamma sum |u|^(p+1)] / sum u^2  (2D classes)
+    w_reg_f: float = 0.0                       # w / (mean u^2 + reg_f_eps)      src/gross_pitaevskii_2D.py:201
+    reg_f_eps: float = 1e-2
+    w_reg_lam: float = 0.0                     # w / (lambda^2 + reg_lam_eps)    src/gross_pitaevskii_2D.py:204
+    reg_lam_eps: float = 1e-6
     dx: float = 1.0                            # quadrature weight
     n_global: int = 0                          # N used in the means (0 -> len(x))
 
@@ -288,6 +294,23 @@ def riesz_coefs(pb: "Problem"):
     return 0.5, 1.0, gi, True                  # Paper nb c6:L163-177
 
 
+def energy_numerator(pb: "Problem", tot: dict) -> float:
+    """c sum |grad u|^2 + sum V u^2 + gamma sum |u|^(p+1) from the three energy sums (filed with the Riesz coefficients on them)."""
+    ak, ap, _, _ = riesz_coefs(pb)
+    ci = 0.5 * (pb.p + 1) if pb.riesz_kind == RIESZ_VARIATIONAL else float(pb.p + 1)
+    return pb.kinetic_coeff * tot['rz_k'] / ak + tot['rz_p'] / ap + ci * tot['rz_i']
+
+
+def reg_terms(pb: "Problem", den: float, lam: float, N: int) -> float:
+    """src/gross_pitaevskii_2D.py:197-211: L_f = w / (mean u^2 + eps), L_lambda = w / (lambda^2 + eps)"""
+    r = 0.0
+    if pb.w_reg_f != 0.0:
+        r += pb.w_reg_f / (den / N + pb.reg_f_eps)
+    if pb.w_reg_lam != 0.0:
+        r += pb.w_reg_lam / (lam * lam + pb.reg_lam_eps)
+    return r
+
+
 def _ipow(u, p: int):
     r = np.ones_like(u)
     for _ in range(p):
@@ -366,7 +389,7 @@ def loss_and_grad(pb: Problem, flat: np.ndarray, x: np.ndarray, x_bc: Optional[n
     n_orth = 0 if orth is None else orth.shape[0]
     for j in range(n_orth):
         sums[f'orth{j}'] = float((orth[j].astype(dt)[:, None] * u).sum(dtype=acc))
-    if pb.w_riesz != 0.0:                                        # Paper nb c6:L163-174 (dx cancels in the quotient) ; 2D: src/...2D.py:112-151
+    if pb.w_riesz != 0.0 or pb.lambda_kind == LAMBDA_ENERGY:     # Paper nb c6:L163-174 (dx cancels in the quotient) ; 2D: src/...2D.py:112-151,192
         ak, ap, ai, _ = riesz_coefs(pb)
         sums['rz_k'] = float((dt.type(ak) * (U[1:1 + d] ** 2).sum(axis=0)).sum(dtype=acc))
         sums['rz_p'] = float((dt.type(ap) * V[:, None] * u * u).sum(dtype=acc))
@@ -399,7 +422,11 @@ def loss_and_grad(pb: Problem, flat: np.ndarray, x: np.ndarray, x_bc: Optional[n
         tot = shard_sums
     else:
         tot = sums
-    lam = dt.type(tot['num'] / tot['den'])                       # :186-188
+    if pb.lambda_kind == LAMBDA_ENERGY:                          # src/gross_pitaevskii_2D.py:192 (per-point reading of quirk Q1)
+        assert not pb.complex_psi and pb.n_out == 1 and pb.p % 2 == 1
+        lam = dt.type(energy_numerator(pb, tot) / tot['den'])
+    else:
+        lam = dt.type(tot['num'] / tot['den'])                   # :186-188
     r = Hu - lam * u                                             # :191
     sr2 = float((r * r).sum(dtype=acc))
     I = dt.type(tot['den']) * dt.type(pb.dx)                     # :216 torch.sum(u**2)*dx
@@ -428,7 +455,7 @@ def loss_and_grad(pb: Problem, flat: np.ndarray, x: np.ndarray, x_bc: Optional[n
         E_rz = (tot['rz_k'] + tot['rz_p'] + fI * tot['rz_i'] - pb.omega_rot * tot.get('rz_l', 0.0)) / (tot['den'] if rz_norm else 1.0)
     else:
         E_rz = 0.0
-    res.update(L_norm=L_norm, L_bc=L_bc, L_orth=L_orth, L_sym=L_sym, L_riesz=E_rz)
+    res.update(L_norm=L_norm, L_bc=L_bc, L_orth=L_orth, L_sym=L_sym, L_riesz=E_rz, L_reg=reg_terms(pb, tot['den'], float(lam), N))
     if not want_grad:
         return res
     # ---- seeds ----
@@ -483,6 +510,23 @@ def loss_and_grad(pb: Problem, flat: np.ndarray, x: np.ndarray, x_bc: Optional[n
             Ub[2, :, 0] += wz * (Om * xx * u[:, 1]) / dnm        # d<L_z>/d(d_y psi_r) = -x psi_i
             Ub[1, :, 1] += wz * (Om * yy * u[:, 0]) / dnm        # d<L_z>/d(d_x psi_i) = -y psi_r
             Ub[2, :, 1] += wz * (-Om * xx * u[:, 0]) / dnm       # d<L_z>/d(d_y psi_i) = x psi_r
+    if pb.lambda_kind == LAMBDA_ENERGY or pb.w_reg_f != 0.0:
+        # lambda is not the Rayleigh quotient of the residual's operator: d loss / d lambda = -2 w_pde / N sum r u (+ d L_lambda / d lambda)
+        # reaches u and grad u through d lambda / d u (the branch SURVEY quirk Q10 says must be kept for the 2D classes)
+        den = tot['den']
+        if pb.lambda_kind == LAMBDA_ENERGY:
+            lf = float(lam)
+            lam_bar = -2.0 * pb.w_pde / N * (tot['num'] - lf * den)
+            if pb.w_reg_lam != 0.0:
+                lam_bar += -2.0 * pb.w_reg_lam * lf / (lf * lf + pb.reg_lam_eps) ** 2
+            lb = dt.type(lam_bar / den)
+            sgn = np.sign(u + (u == 0))
+            Ub[0] = Ub[0] + lb * (2 * V[:, None] * u + g * dt.type(pb.p + 1) * sgn * _ipow(np.abs(u), pb.p) - 2 * lam * u)
+            for k in range(d):
+                Ub[1 + k] = Ub[1 + k] + lb * dt.type(2 * pb.kinetic_coeff) * U[1 + k]
+        if pb.w_reg_f != 0.0:
+            q = den / N + pb.reg_f_eps
+            Ub[0] = Ub[0] + dt.type(-2.0 * pb.w_reg_f / (q * q * N)) * u
     if pb.complex_psi and pb.omega_rot != 0.0:
         Om = dt.type(pb.omega_rot)
         xx, yy = x[:, 0], x[:, 1]
@@ -520,9 +564,9 @@ def assemble(pb: Problem, res: dict, sum_r2_total: Optional[float] = None, n_glo
     sr2 = res['sum_r2'] if sum_r2_total is None else sum_r2_total
     pde = sr2 / N
     total = (pb.w_pde * pde + pb.w_bc * res['L_bc'] + pb.w_norm * res['L_norm']
-             + pb.w_sym * res['L_sym'] + pb.w_orth * res['L_orth'] + pb.w_riesz * res.get('L_riesz', 0.0))
+             + pb.w_sym * res['L_sym'] + pb.w_orth * res['L_orth'] + pb.w_riesz * res.get('L_riesz', 0.0) + res.get('L_reg', 0.0))
     return dict(loss=total, pde=pde, bc=res['L_bc'], norm=res['L_norm'], sym=res['L_sym'],
-                orth=res['L_orth'], mu=res['lam'], riesz=res.get('L_riesz', 0.0))
+                orth=res['L_orth'], mu=res['lam'], riesz=res.get('L_riesz', 0.0), reg=res.get('L_reg', 0.0))
 
 
 def full_loss_and_grad(pb: Problem, flat, x, x_bc=None, bc_target=None, V_pre=None, orth=None, base_pre=None):

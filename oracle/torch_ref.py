@@ -153,6 +153,11 @@ def epoch_losses(pb: go.Problem, net: nn.Sequential, X: torch.Tensor, x_bc=None,
     num = torch.mean((u * Hu).sum(dim=1, keepdim=True))      # :186
     den = torch.mean((u * u).sum(dim=1, keepdim=True))       # :187
     lam = num / den
+    if getattr(pb, 'lambda_kind', go.LAMBDA_RAYLEIGH) == go.LAMBDA_ENERGY:
+        # src/gross_pitaevskii_2D.py:192  lambda_pde = mean(u_x^2 + u_y^2 + V u^2 + g u^4) / mean(u^2), read per point (quirk Q1: the
+        # reference's own tensors broadcast to [N,N]; with ONE point per call the two readings coincide -- tests/golden/make_golden_2d.py)
+        e_dens = pb.kinetic_coeff * (grads1[0] ** 2).sum(dim=1, keepdim=True) + V * u ** 2 + pb.gamma * u ** (pb.p + 1)
+        lam = torch.mean(e_dens) / torch.mean(u ** 2)
     if detach_lambda:
         lam = lam.detach()
     r = Hu - lam * u                                         # :191
@@ -161,6 +166,14 @@ def epoch_losses(pb: go.Problem, net: nn.Sequential, X: torch.Tensor, x_bc=None,
     norm = (integral - 1.0) ** 2
     total = pb.w_pde * pde + pb.w_norm * norm
     pieces = dict(pde=pde, norm=norm, lam=lam, u=u, r=r, Hu=Hu, nn=u_pred)
+    reg = 0.0
+    if getattr(pb, 'w_reg_f', 0.0) != 0.0:                   # src/gross_pitaevskii_2D.py:201  L_f = 1 / (mean(u^2) + 1e-2)
+        reg = reg + pb.w_reg_f / (torch.mean(u ** 2) + pb.reg_f_eps)
+    if getattr(pb, 'w_reg_lam', 0.0) != 0.0:                 # :204  L_lambda = 1 / (lambda^2 + 1e-6)
+        reg = reg + pb.w_reg_lam / (lam ** 2 + pb.reg_lam_eps)
+    if not isinstance(reg, float):
+        total = total + reg
+        pieces['reg'] = reg
     if getattr(pb, 'w_riesz', 0.0) != 0.0:
         kind = getattr(pb, 'riesz_kind', go.RIESZ_PAPER)
         if kind == go.RIESZ_PAPER and d == 1:                # Notebooks/Paper/Gross_Pitaevskii_1D_Harmonic.ipynb c6:L157-177, literally

@@ -136,3 +136,19 @@ def stage_divergence(pb, start_flat, X, xb, hist, K, sched, lr, **opt):
     dm = np.array([abs(hist[k]["mu"] - tr[k]["mu"]) for k in range(K)])
     dlr = np.array([abs(hist[k]["lr"] - tr[k]["lr"]) for k in range(K)])
     return dl, dm, dlr
+
+
+# ---- the 2D classes' loss (tests/golden/make_golden_2d_class.py) --------------------------------------------------------------------
+CLASS2D = ["fx_2d_class_32x2_g100.npz", "fx_2d_class_64x4_g500.npz", "fx_2d_class_100x3_g100.npz"]
+
+
+def gaussian_2d(x, V0=1.0, x0=np.pi / 2, y0=np.pi / 2, sigma=0.5):
+    """compute_potential of the 2D classes (src/gross_pitaevskii_2D.py:244-274)"""
+    return V0 * np.exp(-((x[:, 0] - x0) ** 2 + (x[:, 1] - y0) ** 2) / (2 * sigma ** 2))
+
+
+def problem_from_class2d(fx, n_global=0) -> go.Problem:
+    """src/gross_pitaevskii_2D.py:215-242: 10 mean(u_bc^2) + Riesz sum + mean(r^2) + 1/(mean u^2 + 1e-2) + 1/(lambda^2 + 1e-6), energy-functional lambda"""
+    return go.Problem(layers=[int(v) for v in fx["layers"]], activation=0, kinetic_coeff=1.0, potential=go.POT_PRECOMPUTED, gamma=float(fx["g"]), p=3,
+                      abs_power=True, w_pde=1.0, w_bc=10.0, w_norm=0.0, w_riesz=1.0, riesz_kind=go.RIESZ_SUM, lambda_kind=go.LAMBDA_ENERGY,
+                      w_reg_f=1.0, reg_f_eps=1e-2, w_reg_lam=1.0, reg_lam_eps=1e-6, dx=1.0, n_global=n_global)

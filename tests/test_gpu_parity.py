@@ -28,7 +28,8 @@ def cfg_from_problem(pb: go.Problem, **kw) -> GPEConfig:
              base_mode=pb.base_mode, base_deriv=pb.base_deriv, perturb_scale=pb.perturb_scale,
              bc_nn_scale=pb.bc_nn_scale, w_pde=pb.w_pde, w_bc=pb.w_bc, w_norm=pb.w_norm, w_sym=pb.w_sym,
              w_orth=pb.w_orth, sym_sign=pb.sym_sign, dx=pb.dx, n_global=pb.n_global, base_kind=pb.base_kind,
-             envelope=pb.envelope, box_L=pb.box_L, env_L=pb.env_L, w_riesz=pb.w_riesz, riesz_kind=pb.riesz_kind, net_kind=pb.net_kind)
+             envelope=pb.envelope, box_L=pb.box_L, env_L=pb.env_L, w_riesz=pb.w_riesz, riesz_kind=pb.riesz_kind, net_kind=pb.net_kind,
+             lambda_kind=pb.lambda_kind, w_reg_f=pb.w_reg_f, reg_f_eps=pb.reg_f_eps, w_reg_lam=pb.w_reg_lam, reg_lam_eps=pb.reg_lam_eps)
     d.update(kw)
     return GPEConfig(**d)
 
@@ -95,6 +96,19 @@ CASES = {
                                                    w_riesz=1.0, riesz_kind=go.RIESZ_VARIATIONAL, dx=36 / 400), 400, True),
     "3d_riesz_variational": (dict(layers=[3, 128, 128, 128, 1], gamma=100.0, omega=(1.0, 1.4, 2.0), w_riesz=1.0,
                                   riesz_kind=go.RIESZ_VARIATIONAL, dx=0.01), 500, True),
+    # the 2D classes' loss (src/gross_pitaevskii_2D.py:154-242): energy-functional lambda (its gradient branch is carried through the reverse
+    # pass), 1/(mean u^2 + eps) and 1/(lambda^2 + eps) regularisers, with and without the unnormalised Riesz sum (which dwarfs the rest at g = 500)
+    "2d_class_loss_64x4": (dict(layers=[2, 64, 64, 64, 64, 1], gamma=500.0, kinetic_coeff=1.0, pot_scale=1.0, w_norm=0.0, w_riesz=1.0,
+                                riesz_kind=go.RIESZ_SUM, lambda_kind=go.LAMBDA_ENERGY, w_reg_f=1.0, w_reg_lam=1.0, abs_power=True, dx=1.0), 777, True),
+    "2d_energy_lambda_regs_64x4": (dict(layers=[2, 64, 64, 64, 64, 1], gamma=100.0, kinetic_coeff=1.0, pot_scale=1.0, w_norm=0.0,
+                                        lambda_kind=go.LAMBDA_ENERGY, w_reg_f=1.0, w_reg_lam=1.0, dx=1.0), 500, True),
+    "2d_energy_lambda_128x3": (dict(layers=[2, 128, 128, 128, 1], gamma=100.0, lambda_kind=go.LAMBDA_ENERGY, w_reg_lam=0.5, reg_lam_eps=1e-3,
+                                    dx=0.01), 300, True),
+    "3d_energy_lambda_p5_256x2": (dict(layers=[3, 256, 256, 1], gamma=3.0, p=5, omega=(1.0, 1.4, 2.0), lambda_kind=go.LAMBDA_ENERGY,
+                                       w_riesz=0.5, riesz_kind=go.RIESZ_VARIATIONAL, dx=0.01), 130, True),
+    "1d_reg_f_rayleigh": (dict(layers=[1, 32, 32, 32, 1], gamma=2.0, base_mode=0, w_reg_f=0.5, reg_f_eps=0.05, dx=12 / 299), 300, True),
+    "2d_energy_lambda_N1": (dict(layers=[2, 64, 64, 1], gamma=3.0, kinetic_coeff=1.0, pot_scale=1.0, w_norm=0.0, lambda_kind=go.LAMBDA_ENERGY,
+                                 w_reg_f=1.0, w_reg_lam=1.0, dx=1.0), 1, True),
     # residual-block networks (refine/box_to_gaussian_pinn_simulation.py:52-63,100-130): generic set
     "1d_residual_64x2blocks": (dict(layers=[1, 64, 64, 64, 1], net_kind=go.NET_RESIDUAL, activation=1, kinetic_coeff=1.0,
                                     potential=go.POT_GAUSSIAN, pot_a=0.5, gamma=3.0, p=4, base_mode=1, perturb_scale=0.05, dx=0.03), 333, False),
@@ -164,7 +178,7 @@ def test_step_matches_oracle(name, path):
     sc = eng.step()
     # a single point makes mu = u*Hu/u^2 a quotient of two cancelling O(1e-2) sums: fp32 round-off is 10x larger there
     f = 10.0 if N < 4 else 1.0
-    for k, tol in (("mu", 2e-5), ("loss", 1e-4), ("pde", 1e-4), ("bc", 1e-4), ("norm", 2e-4), ("sym", 1e-4), ("riesz", 1e-4)):
+    for k, tol in (("mu", 2e-5), ("loss", 1e-4), ("pde", 1e-4), ("bc", 1e-4), ("norm", 2e-4), ("sym", 1e-4), ("riesz", 1e-4), ("reg", 1e-4)):
         assert abs(sc[k] - osc[k]) <= f * tol * max(abs(osc[k]), 1e-6), (k, sc[k], osc[k])
     assert abs(rs["loss"] - osc["loss"]) <= f * 1e-4 * abs(osc["loss"])
     grad = eng.get_grad()
@@ -869,6 +883,39 @@ def test_golden_2d_reference_points(name):
         eng.bind_points(xt, V=torch.as_tensor(fx["V"].astype(np.float32), device="cuda"))
         sc, _, _ = eng.residual()
         assert abs(sc["riesz"] - float(fx["riesz_all"])) < 2e-5 * abs(float(fx["riesz_all"])), path
+        eng.close()
+
+
+@pytest.mark.parametrize("name", H.CLASS2D)
+def test_golden_2d_class_loss_and_gradient(name):
+    """The 2D classes' whole loss (src/gross_pitaevskii_2D.py:215-242 = src/gross_pitaevskii_2D_minimal.py:201-222) through the C ABI, one
+    collocation point per call like the golden generator (quirk Q1 inert): total, lambda (energy functional), pde + regularisers, Riesz sum,
+    10 x boundary mean and the gradient of loss.backward(), on both kernel sets."""
+    fx = H.load_fx(name)
+    pb = H.problem_from_class2d(fx, n_global=1)
+    layers = [int(v) for v in fx["layers"]]
+    xb = torch.as_tensor(fx["x_bc"], device="cuda")
+    for path in ("generic", "fused"):
+        if path == "fused" and layers[1] == 100:
+            continue
+        eng = Engine(cfg_from_problem(pb, path=PATHS[path], clip_norm=0.0))
+        assert eng.active_path == PATHS[path]
+        worst = 0.0
+        for k in range(fx["x"].shape[0]):
+            x = fx["x"][k:k + 1]
+            eng.set_params(fx["flat0"])
+            eng.reset_optimizer(1e-3)
+            eng.bind_points(torch.as_tensor(x, device="cuda"), V=torch.as_tensor(H.gaussian_2d(x).astype(np.float32), device="cuda"))
+            eng.bind_boundary(xb)
+            sc = eng.step()
+            # one point: lambda is a quotient by u^2 and the residual a cancelling sum -- fp32 round-off of the jets enters 10x amplified
+            assert abs(sc["mu"] / fx["lam"][k] - 1) < 2e-4, (path, k, sc["mu"], fx["lam"][k])
+            assert abs(sc["riesz"] / fx["riesz"][k] - 1) < 5e-5, (path, k)
+            assert abs(10.0 * sc["bc"] / fx["bc_loss"][k] - 1) < 5e-5, (path, k)
+            assert abs((sc["pde"] + sc["reg"]) / fx["pde_loss"][k] - 1) < 2e-3, (path, k, sc["pde"], sc["reg"], fx["pde_loss"][k])
+            assert abs(sc["loss"] / fx["total"][k] - 1) < 5e-4, (path, k, sc["loss"], fx["total"][k])
+            worst = max(worst, H.rel_err(eng.get_grad(), fx["grad"][k]))
+        assert worst < 1e-3, (path, worst)
         eng.close()
 
 

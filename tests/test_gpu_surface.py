@@ -550,3 +550,72 @@ def test_vary_beta_driver_against_reference_run(flavour):
     # the first recorded loss of the first stage is fixed by the ansatz and the (pre-trained or initialised) network
     b0 = betas[0]
     assert abs(hist[mode][b0]["loss"][0] - fx[f"loss_b{b0}"][0]) <= 0.3 * abs(fx[f"loss_b{b0}"][0]) + 1e-6
+
+
+# ---- the 2D classes (src/gross_pitaevskii_2D.py / src/gross_pitaevskii_2D_minimal.py) ------------------------------------------------
+@pytest.mark.parametrize("name,seed", [("fx_2d_class_32x2_g100.npz", 0), ("fx_2d_class_64x4_g500.npz", 1)])
+def test_pinn2d_class_surface_against_golden(name, seed):
+    """The drop-in 2D class called the way the reference's scripts call theirs -- GrossPitaevskiiPINN(layers, g=...), apply(initialize_weights),
+    loss / total_loss(x, x_bc, u_bc), pde_loss(inputs, predictions) -> (loss, residual, lambda), riesz_loss(predictions, inputs),
+    boundary_loss(x_bc, y_bc), compute_potential -- against the numbers of the reference's own class from the same seed, one collocation point
+    per call (tests/golden/make_golden_2d_class.py: quirk Q1 is inert there)."""
+    import gpe_pinn
+    fx = H.load_fx(name)
+    layers = [int(v) for v in fx["layers"]]
+    for ns in (gpe_pinn.pinn2d, gpe_pinn.pinn2d_minimal):
+        torch.manual_seed(seed)
+        model = ns.GrossPitaevskiiPINN(layers, g=float(fx["g"]))
+        model.apply(ns.initialize_weights)
+        np.testing.assert_array_equal(model._flat, fx["flat0"])
+        assert list(model.state_dict().keys())[:2] == ["network.0.weight", "network.0.bias"] and model.g == float(fx["g"])
+        xb = torch.as_tensor(fx["x_bc"], device="cuda")
+        ub = torch.zeros((xb.shape[0], 1), device="cuda")
+        for k in (0, 3, fx["x"].shape[0] - 1):
+            xi = torch.as_tensor(fx["x"][k:k + 1], device="cuda")
+            V = model.compute_potential(xi)
+            assert tuple(V.shape) == (1,) and abs(float(V) - float(H.gaussian_2d(fx["x"][k:k + 1].astype(np.float64))[0])) < 1e-6
+            u = model.forward(xi)
+            assert abs(float(u) - fx["u"][k]) < 2e-6 * max(1.0, abs(fx["u"][k]))
+            pde, resid, lam = model.pde_loss(xi, u)
+            assert tuple(resid.shape) == (1, 1)
+            assert abs(float(lam) / fx["lam"][k] - 1) < 2e-4
+            assert abs(float(pde) / fx["pde_loss"][k] - 1) < 2e-3
+            assert abs(float(resid) - fx["residual"][k]) < 2e-3 * max(abs(fx["residual"][k]), abs(fx["lam"][k] * fx["u"][k]))
+            assert abs(float(model.riesz_loss(u, xi)) / fx["riesz"][k] - 1) < 5e-5
+            assert abs(float(model.boundary_loss(xb, ub)) / fx["bc_loss"][k] - 1) < 5e-5
+            for fn in (model.loss, model.total_loss):
+                assert abs(float(fn(xi, xb, ub)) / fx["total"][k] - 1) < 5e-4
+        model.close()
+
+
+def test_pinn2d_train_pinn_against_the_oracle_trajectory():
+    """train_pinn(N_u, N_f, layers, epochs) of src/gross_pitaevskii_2D_minimal.py:278-327 on the engine: seeded weights and training set are the
+    reference's (CPU test: bit for bit), every epoch's record is kept, and the first epochs follow the fp64 oracle stepped from the same start
+    (Adam lr 1e-3, no clipping, constant lr) with a bound that grows with the epoch; the loss goes down; lambda stays positive."""
+    import gpe_pinn
+    from oracle import gpe_oracle as go
+    torch.manual_seed(4)
+    np.random.seed(4)
+    layers, epochs = [2, 32, 32, 32, 1], 120
+    model = gpe_pinn.pinn2d_minimal.train_pinn(N_u=40, N_f=600, layers=layers, epochs=epochs, verbose=False)
+    np.random.seed(4)
+    X_f, X_u, _ = gpe_pinn.pinn2d_minimal.prepare_training_data(40, 600)
+    assert len(model.history) == epochs and model._flat.shape == model.start_flat.shape
+    pb = go.Problem(layers=layers, activation=0, kinetic_coeff=1.0, potential=go.POT_PRECOMPUTED, gamma=100.0, p=3, abs_power=True, w_pde=1.0,
+                    w_bc=10.0, w_norm=0.0, w_riesz=1.0, riesz_kind=go.RIESZ_SUM, lambda_kind=go.LAMBDA_ENERGY, w_reg_f=1.0, w_reg_lam=1.0, dx=1.0)
+    X32 = X_f.astype(np.float32).astype(np.float64)
+    st = go.OptState(lr0=1e-3, clip_norm=0.0)
+    K = 12
+    _, tr = go.train_steps(pb, st, model.start_flat.astype(np.float64), X32, K, X_u.astype(np.float32).astype(np.float64),
+                           V_pre=H.gaussian_2d(X32), dtype=np.float64)
+    for k in range(K):
+        h = model.history[k]
+        bound = 2e-5 * (1 + k)
+        assert abs(h["loss"] / tr[k]["loss"] - 1) < bound, (k, h["loss"], tr[k]["loss"])
+        assert abs(h["mu"] / tr[k]["mu"] - 1) < 10 * bound, (k, h["mu"], tr[k]["mu"])
+        assert abs(h["riesz"] / tr[k]["riesz"] - 1) < bound and abs(h["reg"] / tr[k]["reg"] - 1) < 10 * bound
+    loss = model.history["loss"]
+    assert loss[-1] < 0.5 * loss[0] and np.all(np.isfinite(loss)) and np.all(model.history["mu"] > 0)
+    X, Y, u = gpe_pinn.pinn2d_minimal.solution_on_grid(model, num_grid_pts=20)
+    assert u.shape == (20, 20) and np.all(np.isfinite(u))
+    model.close()

@@ -247,6 +247,58 @@ def test_2d_jets_and_Hu_against_reference_points(name):
     assert np.abs(lam_o[big] / fx["lam"][big] - 1).max() < 2e-4
 
 
+@pytest.mark.parametrize("name", H.CLASS2D)
+def test_2d_class_loss_and_gradient_against_reference_points(name):
+    """tests/golden/make_golden_2d_class.py: model.total_loss(x_k, x_bc, u_bc) of the reference's 2D class with ONE collocation point per call
+    (src/gross_pitaevskii_2D_minimal.py:201-222 = src/gross_pitaevskii_2D.py:215-242) and its loss.backward() gradient, against the fp64 oracle
+    with the energy-functional lambda (its gradient branch kept), both regularisers, the unnormalised Riesz sum and 10 x the boundary mean."""
+    fx = H.load_fx(name)
+    pb = H.problem_from_class2d(fx, n_global=1)
+    flat = fx["flat0"].astype(np.float64)
+    xb = fx["x_bc"].astype(np.float64)
+    worst = 0.0
+    for k in range(fx["x"].shape[0]):
+        x = fx["x"][k:k + 1].astype(np.float64)
+        sc, grad, res = go.full_loss_and_grad(pb, flat, x, xb, V_pre=H.gaussian_2d(x))
+        assert abs(res["psi"][0, 0] - fx["u"][k]) < 2e-6 * max(1.0, abs(fx["u"][k]))
+        assert abs(sc["mu"] / fx["lam"][k] - 1) < 2e-5, (k, sc["mu"], fx["lam"][k])
+        assert abs(sc["riesz"] / fx["riesz"][k] - 1) < 2e-5
+        assert abs(10.0 * sc["bc"] / fx["bc_loss"][k] - 1) < 2e-5
+        assert abs((sc["pde"] + sc["reg"]) / fx["pde_loss"][k] - 1) < 5e-5, (k, sc["pde"], sc["reg"], fx["pde_loss"][k])
+        assert abs(sc["loss"] / fx["total"][k] - 1) < 2e-5
+        worst = max(worst, H.rel_err(grad, fx["grad"][k]))
+    assert worst < 5e-5, worst          # (measured 7e-6: the fixture is fp32 autograd)
+
+
+def test_2d_class_training_set_and_seeded_init_bit_exact():
+    """prepare_training_data of src/gross_pitaevskii_2D_minimal.py:225-261 under np.random.seed, and torch.manual_seed + GrossPitaevskiiPINN(layers)
+    + model.apply(initialize_weights) (:264-275), reproduced bit for bit by the drop-in module."""
+    import torch
+    import gpe_pinn
+    fx = H.load_fx("fx_2d_class_data.npz")
+    np.random.seed(int(fx["seed"]))
+    X_f, X_u, u = gpe_pinn.pinn2d_minimal.prepare_training_data(int(fx["N_u"]), int(fx["N_f"]))
+    np.testing.assert_array_equal(X_f, fx["square_X_f"])
+    np.testing.assert_array_equal(X_u, fx["square_X_u"])
+    np.testing.assert_array_equal(u, fx["square_u"])
+    np.random.seed(5)                                      # the polar flavour (src/gross_pitaevskii_2D.py:277-295; that script needs pyDOE and
+    Xp, Xu, _ = gpe_pinn.pinn2d.prepare_training_data(9, 200)     # cannot be imported here): same stream as pair-at-a-time draws, inside the disk
+    np.random.seed(5)
+    pairs = [(np.random.uniform(0, 2 * np.pi), np.random.uniform(0, np.pi / 2)) for _ in range(200)]
+    np.testing.assert_array_equal(Xp, np.array([[np.pi / 2 + r * np.cos(a), np.pi / 2 + r * np.sin(a)] for a, r in pairs]))
+    assert Xp.shape == (200, 2) and np.all((Xp[:, 0] - np.pi / 2) ** 2 + (Xp[:, 1] - np.pi / 2) ** 2 <= (np.pi / 2) ** 2 + 1e-12)
+    torch.manual_seed(int(fx["init_seed"]))
+    m = gpe_pinn.pinn2d.GrossPitaevskiiPINN([int(v) for v in fx["init_layers"]])
+    m.apply(gpe_pinn.pinn2d.initialize_weights)
+    np.testing.assert_array_equal(m._flat, fx["init_flat"])
+    for fxn, seed in (("fx_2d_class_32x2_g100.npz", 0), ("fx_2d_class_64x4_g500.npz", 1)):
+        f2 = H.load_fx(fxn)
+        torch.manual_seed(seed)
+        m = gpe_pinn.pinn2d_minimal.GrossPitaevskiiPINN([int(v) for v in f2["layers"]], g=float(f2["g"]))
+        m.apply(gpe_pinn.pinn2d_minimal.initialize_weights)
+        np.testing.assert_array_equal(m._flat, f2["flat0"])
+
+
 # ---- a13: seeded initialisation equals the fixtures' flat0 bit for bit -------------------------------------------------------
 def test_advanced_initialization_bit_exact():
     """surface._advanced_init after torch.manual_seed(seed) + default nn.Linear init == the reference's
