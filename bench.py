@@ -423,7 +423,20 @@ def main():
     native = use_dist and args.exchange == "engine"
     xcheck = None
     if native:
-        eng.comm_init(rank, world)
+        # a rank whose communicator cannot be created (librccl missing / ncclCommInitRank error) must not take the job down: every rank
+        # learns of it through the torch.distributed group and the whole job drops to the torch protocol, labelled in the line
+        try:
+            eng.comm_init(rank, world)
+            bad = 0
+        except Exception as ex:                                        # noqa: BLE001 -- reported, then agreed on collectively
+            print(f"bench: rank {rank}: engine RCCL communicator not created ({ex}); falling back to torch.distributed", file=sys.stderr, flush=True)
+            bad = 1
+        flag = torch.tensor([bad], dtype=torch.int32, device=f"cuda:{local_rank}")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()) != 0:
+            native = False
+            xcheck = {"ok": False, "comm_init_failed": True}
+    if native:
         if world > 1 or os.environ.get("GPE_BENCH_FORCE_XCHECK"):     # (the variable: run the check at world 1 too -- tests)
             # the engine-native exchange against the torch.distributed protocol, from the same state, before anything is timed: a
             # mismatch on any rank sends the whole job to the torch protocol (labelled in the line) instead of timing a wrong path

@@ -225,8 +225,14 @@ class Engine:
             key = f"gpe_comm_id/{Engine._comm_seq}"
         Engine._comm_seq += 1
         ident = (C.c_ubyte * capi.GPE_COMM_ID_BYTES)()
+        id_err = None
         if rank == 0:
-            self._chk(self.lib.gpe_comm_unique_id(self._h, ident))
+            try:
+                self._chk(self.lib.gpe_comm_unique_id(self._h, ident))
+            except GPEError as ex:                         # (e.g. librccl not found) -- the other ranks are told below instead of left waiting
+                if store is not None or world <= 1:
+                    raise
+                id_err = ex
         if store is not None:                              # caller's key-value store (set / get)
             if rank == 0:
                 store.set(key, bytes(ident))
@@ -234,8 +240,12 @@ class Engine:
                 C.memmove(ident, _store_get(store, key, timeout, rank), capi.GPE_COMM_ID_BYTES)
         elif world > 1:                                    # default: the initialised torch.distributed group, public API only
             import torch.distributed as dist
-            box = [bytes(ident) if rank == 0 else None]
+            box = [(bytes(ident) if id_err is None else None) if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
+            if id_err is not None:
+                raise id_err
+            if box[0] is None:
+                raise GPEError(capi.GPE_ERR_STATE, "comm_init: rank 0 could not create an ncclUniqueId")
             if rank != 0:
                 C.memmove(ident, box[0], capi.GPE_COMM_ID_BYTES)
         self._chk(self.lib.gpe_comm_init(self._h, ident, int(rank), int(world)))
