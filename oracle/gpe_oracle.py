@@ -576,22 +576,23 @@ def full_loss_and_grad(pb: Problem, flat, x, x_bc=None, bc_target=None, V_pre=No
     return sc, grad, res
 
 
-def sharded_loss_and_grad(pb: Problem, flat, x, x_bc=None, chunk: int = 65536, threads: int = 4):
+def sharded_loss_and_grad(pb: Problem, flat, x, x_bc=None, chunk: int = 65536, threads: int = 4, V_pre=None):
     """full_loss_and_grad of a batch too large to hold its jets at once (bench.py / tests: the oracle on the batch AS TIMED, 10^6
     points): the two-phase data-parallel protocol of loss_and_grad over contiguous chunks -- phase 1 adds the global sums (mu, norm
     integral), phase 2 the chunk gradients with those totals.  Same arithmetic as one call on the whole batch up to the order of
-    the fp64 sums.  Chunks run on a small thread pool (numpy releases the GIL).  Problems without orthogonality targets /
-    precomputed potentials only (what the large workloads use).  -> (scalars, gradient)"""
+    the fp64 sums.  Chunks run on a small thread pool (numpy releases the GIL).  Problems without orthogonality targets (what the
+    large workloads use); a precomputed potential is sliced with the points.  -> (scalars, gradient)"""
     from concurrent.futures import ThreadPoolExecutor
     import dataclasses
     N = x.shape[0]
     pbn = dataclasses.replace(pb, n_global=N)
     bounds = [(a, min(N, a + chunk)) for a in range(0, N, chunk)]
     with ThreadPoolExecutor(max_workers=max(1, threads)) as ex:
-        parts = list(ex.map(lambda ab: loss_and_grad(pbn, flat, x[ab[0]:ab[1]], phase=1), bounds))
+        vp = (lambda a, b: None) if V_pre is None else (lambda a, b: V_pre[a:b])
+        parts = list(ex.map(lambda ab: loss_and_grad(pbn, flat, x[ab[0]:ab[1]], V_pre=vp(*ab), phase=1), bounds))
         tot = {k: float(sum(p[k] for p in parts)) for k in parts[0]}
         # the boundary term is replicated: only the first chunk forms it
-        res = list(ex.map(lambda ib: loss_and_grad(pbn, flat, x[ib[1][0]:ib[1][1]], x_bc if ib[0] == 0 else None, shard_sums=tot),
+        res = list(ex.map(lambda ib: loss_and_grad(pbn, flat, x[ib[1][0]:ib[1][1]], x_bc if ib[0] == 0 else None, V_pre=vp(*ib[1]), shard_sums=tot),
                           enumerate(bounds)))
     r0 = res[0]
     sr2 = float(sum(r['sum_r2'] for r in res))

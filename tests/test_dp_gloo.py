@@ -21,20 +21,22 @@ class OracleShardEngine:
     def __init__(self, pb, flat, x, x_bc, world):
         self.pb, self.flat, self.x, self.x_bc, self.world = pb, flat.astype(np.float32), x.astype(np.float32), x_bc, world
         P = go.param_count(pb.layers)
-        self.exchange_sums = torch.zeros(8, dtype=torch.float64)
+        self.exchange_sums = torch.zeros(12, dtype=torch.float64)        # the engine's layout (csrc/gpe_common.h: S_NUM .. S_RZ_L, S_COUNT = 12)
         self.exchange_grad = torch.zeros(P + 4, dtype=torch.float32)
         self.opt = go.OptState(lr0=1e-3)
         self.trace = []
 
+    SLOT = dict(num=0, den=1, sym=2, rz_k=7, rz_p=8, rz_i=9, rz_l=10)
+
     def step_begin(self):
         s = go.loss_and_grad(self.pb, self.flat, self.x, self.x_bc, phase=1)
         self.exchange_sums.zero_()
-        self.exchange_sums[0], self.exchange_sums[1] = s["num"], s["den"]
-        if "sym" in s:
-            self.exchange_sums[2] = s["sym"]
+        for k, i in self.SLOT.items():
+            if k in s:
+                self.exchange_sums[i] = s[k]
 
     def step_backward(self):
-        tot = dict(num=float(self.exchange_sums[0]), den=float(self.exchange_sums[1]), sym=float(self.exchange_sums[2]))
+        tot = {k: float(self.exchange_sums[i]) for k, i in self.SLOT.items()}
         self.res = go.loss_and_grad(self.pb, self.flat, self.x, self.x_bc, shard_sums=tot, phase=2)
         g = self.res["grad_local"] + self.res["grad_bc"] / self.world      # boundary batch is replicated
         self.exchange_grad[:-4] = torch.from_numpy(g.astype(np.float32))
@@ -57,20 +59,28 @@ def _free_port():
     return p
 
 
-def _problem(N):
+def _problem(N, kind="1d_sym"):
+    if kind == "2d_class_loss":          # src/gross_pitaevskii_2D.py:154-242: the lambda branch of the gradient is built from the EXCHANGED energy sums
+        return go.Problem(layers=[2, 16, 16, 1], gamma=20.0, kinetic_coeff=1.0, pot_scale=1.0, w_norm=0.0, w_riesz=0.05, riesz_kind=go.RIESZ_SUM,
+                          lambda_kind=go.LAMBDA_ENERGY, w_reg_f=1.0, w_reg_lam=1.0, dx=1.0, n_global=N)
     return go.Problem(layers=[1, 16, 16, 1], gamma=3.0, p=3, base_mode=0, dx=12.0 / (N - 1), w_sym=5.0, n_global=N)
 
 
-def _worker(rank, world, port, N, steps, out):
+def _data(N, kind):
+    rng = np.random.default_rng(0)
+    pb = _problem(N, kind)
+    flat = rng.normal(0, 0.3, go.param_count(pb.layers))
+    if kind == "2d_class_loss":
+        return pb, flat, rng.uniform(-2, 2, (N, 2)), rng.uniform(-2, 2, (5, 2))
+    return pb, flat, np.linspace(-6, 6, N).reshape(-1, 1), np.array([[-6.0], [6.0]])
+
+
+def _worker(rank, world, port, N, steps, out, kind="1d_sym"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
-    rng = np.random.default_rng(0)
-    pb = _problem(N)
-    flat = rng.normal(0, 0.3, go.param_count(pb.layers))
-    x = np.linspace(-6, 6, N).reshape(-1, 1)
-    x_bc = np.array([[-6.0], [6.0]])
+    pb, flat, x, x_bc = _data(N, kind)
     eng = OracleShardEngine(pb, flat, shard_points(x, rank, world), x_bc, world)
     for _ in range(steps):
         distributed_step(eng)
@@ -92,18 +102,16 @@ def test_shard_bounds_cover_everything():
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_step_equals_full_batch(tmp_path):
+@pytest.mark.parametrize("kind", ["1d_sym", "2d_class_loss"])
+def test_two_rank_step_equals_full_batch(tmp_path, kind):
     N, steps, world = 301, 4, 2                      # odd N: ragged shards
     out = str(tmp_path / "dp.npz")
-    mp.spawn(_worker, args=(world, _free_port(), N, steps, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), N, steps, out, kind), nprocs=world, join=True)
     got = np.load(out)
     # single-process reference: the same oracle on the full batch
-    rng = np.random.default_rng(0)
-    pb = _problem(N)
-    flat = rng.normal(0, 0.3, go.param_count(pb.layers))
-    x = np.linspace(-6, 6, N).reshape(-1, 1)
+    pb, flat, x, x_bc = _data(N, kind)
     st = go.OptState(lr0=1e-3)
-    ref_flat, trace = go.train_steps(pb, st, flat, x, steps, x_bc=np.array([[-6.0], [6.0]]))
+    ref_flat, trace = go.train_steps(pb, st, flat, x, steps, x_bc=x_bc)
     np.testing.assert_allclose(got["loss"], [t["loss"] for t in trace], rtol=2e-5)
     np.testing.assert_allclose(got["mu"], [t["mu"] for t in trace], rtol=2e-5)
     np.testing.assert_allclose(got["gn"], [t["grad_norm"] for t in trace], rtol=2e-4)

@@ -214,10 +214,13 @@ def test_fused_and_generic_agree_full_size():
     assert H.rel_err(gb, ga) < 2e-4
 
 
-def test_shard_additivity_two_engines_one_gpu():
+@pytest.mark.parametrize("extra", [{}, dict(kinetic_coeff=1.0, pot_scale=1.0, w_norm=0.0, w_riesz=0.05, riesz_kind=go.RIESZ_SUM,
+                                            lambda_kind=go.LAMBDA_ENERGY, w_reg_f=1.0, w_reg_lam=1.0)], ids=["north_star_loss", "2d_class_loss"])
+def test_shard_additivity_two_engines_one_gpu(extra):
     """world_size = 2 emulated on one GPU: two engines own the two halves of the points, the exchange buffers are
-    summed by hand (what the RCCL all-reduce does), and the result must equal the single-engine step."""
-    kw = dict(layers=[2, 64, 64, 64, 1], gamma=50.0, dx=0.01)
+    summed by hand (what the RCCL all-reduce does), and the result must equal the single-engine step.  Second case: the 2D classes' loss,
+    whose lambda branch is built from the exchanged energy sums."""
+    kw = dict(layers=[2, 64, 64, 64, 1], gamma=50.0, dx=0.01, **extra)
     N = 4099
     x, flat, x_bc = _inputs(kw, N)
     pb = go.Problem(**kw, n_global=N)
@@ -719,6 +722,36 @@ def test_large_batch_launch_configuration_against_the_oracle():
     assert H.rel_err(g, ograd) < 5e-5
 
 
+def test_large_batch_2d_class_loss_against_the_oracle():
+    """The reference's 2D class loss (energy-functional lambda with its gradient branch, both regularisers, Riesz sum, 10 x boundary mean:
+    src/gross_pitaevskii_2D.py:154-242) at a large batch -- 300 001 points in the disk, Gaussian potential handed over as an array, head and
+    seed kernels in their own launches -- against the fp64 oracle (sharded evaluation): the double-precision point sums the lambda branch is
+    made of hold at this size."""
+    layers = [2, 64, 64, 64, 64, 1]
+    N = 300001
+    rng = np.random.default_rng(11)
+    ang, rad = rng.uniform(0, 2 * np.pi, N), (np.pi / 2) * np.sqrt(rng.uniform(0, 1, N))
+    x = np.stack([np.pi / 2 + rad * np.cos(ang), np.pi / 2 + rad * np.sin(ang)], 1).astype(np.float32)
+    th = np.linspace(0, 2 * np.pi, 500)
+    xb = np.stack([np.pi / 2 + (np.pi / 2) * np.cos(th), np.pi / 2 + (np.pi / 2) * np.sin(th)], 1).astype(np.float32)
+    flat = (rng.normal(0, 1, go.param_count(layers)) * 0.3).astype(np.float32)
+    pb = H.problem_from_class2d(dict(layers=np.array(layers), g=500.0))
+    V = H.gaussian_2d(x.astype(np.float64))
+    eng = Engine(cfg_from_problem(pb, clip_norm=0.0))
+    eng.set_params(flat)
+    eng.bind_points(torch.as_tensor(x, device="cuda"), V=torch.as_tensor(V.astype(np.float32), device="cuda"))
+    eng.bind_boundary(torch.as_tensor(xb, device="cuda"))
+    assert eng.active_path == gpe_pinn.PATH_FUSED and "head" not in eng.active_kernels["fwd"]
+    sc = eng.step()
+    g = eng.get_grad()
+    eng.close()
+    osc, ograd = go.sharded_loss_and_grad(pb, flat.astype(np.float64), x.astype(np.float64), xb.astype(np.float64), chunk=65536, threads=8,
+                                          V_pre=V.astype(np.float32).astype(np.float64))
+    for k, tol in (("loss", 1e-4), ("mu", 2e-5), ("riesz", 1e-4), ("reg", 1e-4), ("pde", 1e-4), ("bc", 1e-4)):
+        assert abs(sc[k] - osc[k]) <= tol * abs(osc[k]), (k, sc[k], osc[k])
+    assert H.rel_err(g, ograd) < 5e-5
+
+
 @pytest.mark.parametrize("layers,sym,sched", [([1, 32, 32, 32, 32, 1], 5.0, go.SCHED_PLATEAU), ([1, 64, 64, 64, 1], 0.0, go.SCHED_COSINE_LOSS),
                                               ([2, 64, 64, 64, 64, 1], 0.0, go.SCHED_CONST)])
 def test_update_kernel_forms_are_bit_identical(layers, sym, sched):
@@ -949,9 +982,11 @@ def test_generic_kernel_variants_agree(kw, N):
 
 
 # ---- native exchange: the engine's own RCCL communicator (world 1 on the one-GPU box: the same code path as N ranks) -----------
+@pytest.mark.parametrize("extra", [{}, dict(kinetic_coeff=1.0, pot_scale=1.0, w_norm=0.0, w_riesz=0.05, riesz_kind=go.RIESZ_SUM,
+                                            lambda_kind=go.LAMBDA_ENERGY, w_reg_f=1.0, w_reg_lam=1.0)], ids=["north_star_loss", "2d_class_loss"])
 @pytest.mark.parametrize("path", ["generic", "fused"])
-def test_native_rccl_step_equals_plain_step(path):
-    kw = dict(layers=[2, 64, 64, 64, 1], gamma=50.0, dx=0.01)
+def test_native_rccl_step_equals_plain_step(path, extra):
+    kw = dict(layers=[2, 64, 64, 64, 1], gamma=50.0, dx=0.01, **extra)
     x, flat, x_bc = _inputs(kw, 3000)
     pb = go.Problem(**kw)
     a = make_engine(pb, flat, x, x_bc, path=PATHS[path])

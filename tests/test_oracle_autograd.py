@@ -143,6 +143,25 @@ def test_orthogonality_definition_and_dp_additivity():
     assert abs(r2[0]["L_orth"] - sc["orth"]) <= 1e-13 * sc["orth"]
 
 
+def test_sharded_oracle_with_the_2d_class_loss_and_a_precomputed_potential():
+    """The sharded evaluation with the terms whose reverse pass needs global sums beyond (num, den): energy-functional lambda, regularisers,
+    Riesz sum; potential handed over as an array."""
+    kw = dict(layers=[2, 16, 16, 1], gamma=100.0, kinetic_coeff=1.0, potential=go.POT_PRECOMPUTED, abs_power=True, w_norm=0.0, w_riesz=1.0,
+              riesz_kind=go.RIESZ_SUM, lambda_kind=go.LAMBDA_ENERGY, w_reg_f=1.0, w_reg_lam=1.0, dx=1.0)
+    rng = np.random.default_rng(5)
+    N = 1000
+    x = rng.uniform(0, np.pi, (N, 2))
+    V = np.exp(-((x[:, 0] - np.pi / 2) ** 2 + (x[:, 1] - np.pi / 2) ** 2) / 0.5)
+    xb = rng.uniform(0, np.pi, (7, 2))
+    flat = rng.normal(0, 0.4, go.param_count(kw["layers"]))
+    pb = go.Problem(**kw)
+    sc, g, _ = go.full_loss_and_grad(pb, flat, x, xb, V_pre=V)
+    sc2, g2 = go.sharded_loss_and_grad(pb, flat, x, xb, chunk=192, threads=2, V_pre=V)
+    for k in ("loss", "mu", "pde", "riesz", "reg", "bc"):
+        assert abs(sc[k] - sc2[k]) <= 1e-12 * abs(sc[k]), k
+    assert np.abs(g - g2).max() <= 1e-11 * np.abs(g).max()
+
+
 def test_sharded_two_phase_oracle_equals_the_single_call():
     """oracle.sharded_loss_and_grad (what bench.py's in-run parity_check and the 540 000-point GPU test run on the batch as timed):
     chunked two-phase evaluation == one call on the whole batch, to the order of the fp64 sums."""
