@@ -476,6 +476,12 @@ struct gpe_engine {
     bool wide = false;             // fused path: reverse pass by the wide kernel set (gpe_wide.h): H = 256 or 128
     bool wide_fwd = false;         // ... and the forward pass too (H = 256, H = 128 in 3D; H = 128 in 1D/2D keeps f_forward_coop: measured)
     int P = 0, Ppad = 0;
+    // width padding: hidden widths without an MFMA kernel instance run zero-padded to the next width that has one.  P counts the
+    // padded network (what the kernels, the optimiser and the gradient exchange see); the caller's flat vector has P_user entries
+    // and umap[i] is the padded index of its i-th entry.  Empty map: no padding, P_user == P.
+    int P_user = 0;
+    std::vector<int> umap;
+    int user_layers[GPE_MAX_LAYERS] = {0};
     float base_norm = 1.f;
     float *theta = nullptr, *am = nullptr, *av = nullptr, *grad = nullptr;   // grad: P + GT_COUNT
     double* dbl = nullptr;         // [S_COUNT sums | LS_COUNT local | 4 misc]
@@ -1369,11 +1375,13 @@ int gpe_active_kernels(gpe_engine* e, char* buf, size_t n) {
             fused_grid(e, b.n, 1, e->coop_wg_per_cu) == (unsigned)g2 && ntiles >= e->share_min_tiles * g2)
             sb = e->pipe_share;
     }
-    snprintf(buf, n, "fwd=%s;bwd=%s;split=fwd %d/1024, bwd %d/1024", f, r, sf, sb);
+    if (e->umap.empty()) snprintf(buf, n, "fwd=%s;bwd=%s;split=fwd %d/1024, bwd %d/1024", f, r, sf, sb);
+    else snprintf(buf, n, "fwd=%s;bwd=%s;split=fwd %d/1024, bwd %d/1024;padded=hidden widths up to %d run as %d", f, r, sf, sb,
+                  *std::max_element(e->user_layers + 1, e->user_layers + e->cfg.n_layers - 1), e->cfg.layers[1]);
     return GPE_OK;
 }
 
-int64_t gpe_param_count(const gpe_engine* e) { return e ? e->P : -1; }
+int64_t gpe_param_count(const gpe_engine* e) { return e ? e->P_user : -1; }   /* the caller's network (hidden widths as given) */
 
 int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine** out) {
     if (!cfg || !out) { g_create_error = "null argument"; return GPE_ERR_INVALID; }
@@ -1408,6 +1416,45 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
     if ((c.w_reg_f != 0.f && !(c.reg_f_eps > 0.f)) || (c.w_reg_lam != 0.f && !(c.reg_lam_eps > 0.f))) CFAIL("regulariser eps must be > 0");
     for (int i = 1; i < c.n_layers - 1; ++i)
         if (c.layers[i] < 1 || c.layers[i] > 1024) CFAIL("hidden width %d out of range", c.layers[i]);
+    // Width padding.  The MFMA kernel sets are instantiated for one hidden width of 32, 64, 128 or 256; other plain-tanh MLPs of width <= 256 --
+    // the 2D scripts' own [2,100,100,100,1] (src/gross_pitaevskii_2D_minimal.py:377), ragged widths -- are run as the next such width with
+    // zero rows / columns / biases in the padding.  A padded unit sees z = 0, gives tanh(0) = 0 with all jets 0, feeds zero outgoing weights
+    // and so receives the gradient 0 exactly on every one of its weights: Adam leaves them at 0 and the network stays the caller's.
+    // (ShiftedTanh gives 1 there and a non-zero gradient on the outgoing weights: not padded.)  GPE_PAD_WIDTH=0 or GPE_PATH_GENERIC: as given.
+    for (int i = 0; i < c.n_layers; ++i) e->user_layers[i] = c.layers[i];
+    {
+        const char* envp = getenv("GPE_PAD_WIDTH");
+        int wmax = 0; bool uni = true;
+        for (int i = 1; i < c.n_layers - 1; ++i) { wmax = std::max(wmax, c.layers[i]); uni = uni && c.layers[i] == c.layers[1]; }
+        const bool native = uni && (wmax == 32 || wmax == 64 || wmax == 128 || wmax == 256);
+        if (!(envp && atoi(envp) == 0) && !native && c.path != GPE_PATH_GENERIC && c.net_kind == GPE_NET_MLP && c.activation == GPE_ACT_TANH &&
+            c.n_layers - 2 >= 2 && wmax <= 256) {
+            // the smallest instantiated width that holds the widest layer and whose kernels take this depth (32 / 64: all weights in LDS)
+            int Hp = 0;
+            for (int h : {32, 64, 128, 256}) {
+                if (h < wmax) continue;
+                if (h <= 64) {
+                    const int Lm = c.n_layers - 3;                        // hidden -> hidden maps
+                    const size_t pp = round_up((size_t)dim * h + h + (size_t)Lm * (h * h + h) + (size_t)h * no + no, 64);
+                    if ((pp + (size_t)(8 + c.n_layers + 2) * h + 8 + 4 * (dim + 2) * F_TILE) * sizeof(float) > 160 * 1024) continue;
+                }
+                Hp = h;
+                break;
+            }
+            int pl[GPE_MAX_LAYERS];
+            for (int i = 0; i < c.n_layers; ++i) pl[i] = (i == 0 || i == c.n_layers - 1) ? c.layers[i] : Hp;
+            int offp = 0;
+            for (int j = 0; j + 1 < c.n_layers; ++j) {
+                const int iu = c.layers[j], ou = c.layers[j + 1], ip = pl[j], op = pl[j + 1];
+                for (int o = 0; o < ou; ++o) for (int i = 0; i < iu; ++i) e->umap.push_back(offp + o * ip + i);
+                offp += ip * op;
+                for (int o = 0; o < ou; ++o) e->umap.push_back(offp + o);
+                offp += op;
+            }
+            e->P_user = (int)e->umap.size();
+            for (int i = 1; i < c.n_layers - 1; ++i) e->cfg.layers[i] = Hp;
+        }
+    }
     NetDesc& nd = e->nd;
     memset(&nd, 0, sizeof nd);
     nd.dim = dim; nd.n_out = no; nd.shift = c.activation == GPE_ACT_TANH_PLUS1 ? 1.f : 0.f;
@@ -1434,6 +1481,7 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
     }
     nd.n_params = off;
     e->P = off;
+    if (e->umap.empty()) e->P_user = off;
     e->Ppad = (int)round_up(off, 64);
     // path selection: fused kernels need >= 2 hidden layers of one width H in {32, 64}
     bool uniform = true;
@@ -1665,34 +1713,56 @@ int gpe_synchronize(gpe_engine* e) {
     return GPE_OK;
 }
 
+// caller's flat vector (P_user entries, hidden widths as given) <-> the engine's (P entries, padded widths)
+static int flat_to_device(gpe_engine* e, float* d_dst, const float* h_user) {
+    if (e->umap.empty()) { HIPCHK(e, hipMemcpyAsync(d_dst, h_user, (size_t)e->P * 4, hipMemcpyHostToDevice, e->stream)); return GPE_OK; }
+    std::vector<float> tmp((size_t)e->P, 0.f);
+    for (int i = 0; i < e->P_user; ++i) tmp[e->umap[i]] = h_user[i];
+    HIPCHK(e, hipMemcpyAsync(d_dst, tmp.data(), (size_t)e->P * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));              // tmp dies with this frame
+    return GPE_OK;
+}
+static int flat_from_device(gpe_engine* e, const float* d_src, float* h_user) {
+    if (e->umap.empty()) { HIPCHK(e, hipMemcpyAsync(h_user, d_src, (size_t)e->P * 4, hipMemcpyDeviceToHost, e->stream)); return GPE_OK; }
+    std::vector<float> tmp((size_t)e->P);
+    HIPCHK(e, hipMemcpyAsync(tmp.data(), d_src, (size_t)e->P * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    for (int i = 0; i < e->P_user; ++i) h_user[i] = tmp[e->umap[i]];
+    return GPE_OK;
+}
+
 int gpe_set_params(gpe_engine* e, const float* h, size_t n) {
     if (!e || !h) return GPE_ERR_INVALID;
-    if ((int64_t)n != e->P) FAIL(e, GPE_ERR_INVALID, "set_params: got %zu floats, model has %d", n, e->P);
-    HIPCHK(e, hipMemcpyAsync(e->theta, h, n * 4, hipMemcpyHostToDevice, e->stream));
+    if ((int64_t)n != e->P_user) FAIL(e, GPE_ERR_INVALID, "set_params: got %zu floats, model has %d", n, e->P_user);
+    int rc = flat_to_device(e, e->theta, h);
+    if (rc) return rc;
     HIPCHK(e, hipStreamSynchronize(e->stream));
     e->packed_dirty = true;
     return GPE_OK;
 }
 int gpe_get_params(gpe_engine* e, float* h, size_t n) {
     if (!e || !h) return GPE_ERR_INVALID;
-    if ((int64_t)n != e->P) FAIL(e, GPE_ERR_INVALID, "get_params: got %zu floats, model has %d", n, e->P);
-    HIPCHK(e, hipMemcpyAsync(h, e->theta, n * 4, hipMemcpyDeviceToHost, e->stream));
+    if ((int64_t)n != e->P_user) FAIL(e, GPE_ERR_INVALID, "get_params: got %zu floats, model has %d", n, e->P_user);
+    int rc = flat_from_device(e, e->theta, h);
+    if (rc) return rc;
     HIPCHK(e, hipStreamSynchronize(e->stream));
     return GPE_OK;
 }
 int gpe_get_grad(gpe_engine* e, float* h, size_t n) {
     if (!e || !h) return GPE_ERR_INVALID;
-    if ((int64_t)n != e->P) FAIL(e, GPE_ERR_INVALID, "get_grad: size mismatch");
-    HIPCHK(e, hipMemcpyAsync(h, e->grad, n * 4, hipMemcpyDeviceToHost, e->stream));
+    if ((int64_t)n != e->P_user) FAIL(e, GPE_ERR_INVALID, "get_grad: size mismatch");
+    int rc = flat_from_device(e, e->grad, h);
+    if (rc) return rc;
     HIPCHK(e, hipStreamSynchronize(e->stream));
     return GPE_OK;
 }
 int gpe_get_adam_state(gpe_engine* e, float* hm, float* hv, size_t n, int64_t* step) {
     if (!e) return GPE_ERR_INVALID;
-    if ((int64_t)n != e->P) FAIL(e, GPE_ERR_INVALID, "get_adam_state: size mismatch");
+    if ((int64_t)n != e->P_user) FAIL(e, GPE_ERR_INVALID, "get_adam_state: size mismatch");
     OptDev h;
-    if (hm) HIPCHK(e, hipMemcpyAsync(hm, e->am, n * 4, hipMemcpyDeviceToHost, e->stream));
-    if (hv) HIPCHK(e, hipMemcpyAsync(hv, e->av, n * 4, hipMemcpyDeviceToHost, e->stream));
+    int rc;
+    if (hm && (rc = flat_from_device(e, e->am, hm))) return rc;
+    if (hv && (rc = flat_from_device(e, e->av, hv))) return rc;
     HIPCHK(e, hipMemcpyAsync(&h, e->od, sizeof h, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     if (step) *step = h.step;
@@ -1700,14 +1770,15 @@ int gpe_get_adam_state(gpe_engine* e, float* hm, float* hv, size_t n, int64_t* s
 }
 int gpe_set_adam_state(gpe_engine* e, const float* hm, const float* hv, size_t n, int64_t step) {
     if (!e || !hm || !hv) return GPE_ERR_INVALID;
-    if ((int64_t)n != e->P) FAIL(e, GPE_ERR_INVALID, "set_adam_state: size mismatch");
+    if ((int64_t)n != e->P_user) FAIL(e, GPE_ERR_INVALID, "set_adam_state: size mismatch");
     OptDev h;
     HIPCHK(e, hipMemcpyAsync(&h, e->od, sizeof h, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     h.step = step;
     h.b1p = pow((double)e->oc.beta1, (double)step); h.b2p = pow((double)e->oc.beta2, (double)step);
-    HIPCHK(e, hipMemcpyAsync(e->am, hm, n * 4, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(e, hipMemcpyAsync(e->av, hv, n * 4, hipMemcpyHostToDevice, e->stream));
+    int rc;
+    if ((rc = flat_to_device(e, e->am, hm))) return rc;
+    if ((rc = flat_to_device(e, e->av, hv))) return rc;
     HIPCHK(e, hipMemcpyAsync(e->od, &h, sizeof h, hipMemcpyHostToDevice, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     return GPE_OK;

@@ -176,7 +176,9 @@ class Engine:
         # caller-owned exchange buffers (so torch.distributed can all-reduce them in place)
         nd = int(self.lib.gpe_exchange_dbl_count())
         self._xdbl = torch.zeros(nd, dtype=torch.float64, device=f"cuda:{self.device}")
-        self._xgrad = torch.zeros(self.n_params + 4, dtype=torch.float32, device=f"cuda:{self.device}")
+        gp, gn = C.c_void_p(), C.c_int64()                  # (length of the engine's gradient message: the network as it RUNS -- hidden
+        self._chk(self.lib.gpe_exchange_grad(self._h, C.byref(gp), C.byref(gn)))     # widths without a kernel instance are zero-padded -- + 4)
+        self._xgrad = torch.zeros(int(gn.value), dtype=torch.float32, device=f"cuda:{self.device}")
         self._chk(self.lib.gpe_use_external_exchange(self._h, C.c_void_p(self._xdbl.data_ptr()), nd,
                                                      C.c_void_p(self._xgrad.data_ptr()), self._xgrad.numel()))
         p, n = C.c_void_p(), C.c_int64()

@@ -113,7 +113,14 @@ CASES = {
     "1d_residual_64x2blocks": (dict(layers=[1, 64, 64, 64, 1], net_kind=go.NET_RESIDUAL, activation=1, kinetic_coeff=1.0,
                                     potential=go.POT_GAUSSIAN, pot_a=0.5, gamma=3.0, p=4, base_mode=1, perturb_scale=0.05, dx=0.03), 333, False),
     "2d_residual_128x3blocks": (dict(layers=[2, 128, 128, 128, 128, 1], net_kind=go.NET_RESIDUAL, gamma=20.0, dx=0.01), 300, False),
-    "2d_100x2_odd_width": (dict(layers=[2, 100, 100, 1], gamma=1.0, dx=0.01), 77, False),
+    # hidden widths without an MFMA kernel instance: the fused path runs them zero-padded to the next instantiated width (plain tanh only);
+    # the generic set takes them as given
+    "2d_100x2_odd_width": (dict(layers=[2, 100, 100, 1], gamma=1.0, dx=0.01), 77, True),
+    "2d_100x3_reference_2d_arch": (dict(layers=[2, 100, 100, 100, 1], gamma=100.0, kinetic_coeff=1.0, pot_scale=1.0, dx=0.01), 500, True),
+    "2d_ragged_48_64_32": (dict(layers=[2, 48, 64, 32, 1], gamma=10.0, dx=0.01), 300, True),
+    "3d_200x2_pads_to_256": (dict(layers=[3, 200, 200, 1], gamma=20.0, omega=(1.0, 1.4, 2.0), dx=0.01), 130, True),
+    "1d_20x3_pads_to_32": (dict(layers=[1, 20, 20, 20, 1], gamma=2.0, base_mode=1, dx=0.03), 333, True),
+    "2d_complex_72x3_pads_to_128": (dict(layers=[2, 72, 72, 72, 2], complex_psi=True, gamma=30.0, omega_rot=0.8, dx=0.02), 200, True),
     "1d_single_hidden": (dict(layers=[1, 64, 1], gamma=1.0, dx=0.01, base_mode=1), 50, False),
 }
 
@@ -896,9 +903,7 @@ def test_golden_2d_reference_points(name):
     fx = H.load_fx(name)
     layers = [int(v) for v in fx["layers"]]
     pb = go.Problem(layers=layers, kinetic_coeff=1.0, potential=go.POT_PRECOMPUTED, gamma=float(fx["g"]), p=3, dx=0.01)
-    for path in ("generic", "fused"):
-        if path == "fused" and layers[1] == 100:
-            continue
+    for path in ("generic", "fused"):            # (H = 100, the reference's own architecture: the fused path runs it padded to 128)
         eng = Engine(cfg_from_problem(pb, w_bc=0.0, path=PATHS[path]))
         eng.set_params(fx["flat0"])
         xt = torch.as_tensor(fx["x"], device="cuda")
@@ -928,9 +933,7 @@ def test_golden_2d_class_loss_and_gradient(name):
     pb = H.problem_from_class2d(fx, n_global=1)
     layers = [int(v) for v in fx["layers"]]
     xb = torch.as_tensor(fx["x_bc"], device="cuda")
-    for path in ("generic", "fused"):
-        if path == "fused" and layers[1] == 100:
-            continue
+    for path in ("generic", "fused"):            # (H = 100: padded to 128 on the fused path)
         eng = Engine(cfg_from_problem(pb, path=PATHS[path], clip_norm=0.0))
         assert eng.active_path == PATHS[path]
         worst = 0.0
@@ -979,6 +982,52 @@ def test_generic_kernel_variants_agree(kw, N):
             assert abs(sc["mu"] - ref[0]["mu"]) <= 1e-5 * abs(ref[0]["mu"]), env
             assert H.rel_err(g, ref[1]) < 2e-5, env
     assert len(seen) == 3, sorted(seen)
+
+
+def test_padded_hidden_widths_train_like_the_network_as_given():
+    """Width padding (hidden widths without an MFMA kernel instance run zero-padded on the fused path): the padded weights must stay exactly
+    zero under Adam, i.e. 40 steps on the padded network are 40 steps on the caller's network -- compared with the generic set, which takes
+    the widths as given; parameters, gradient and Adam state cross the C ABI in the caller's layout and round-trip; GPE_PAD_WIDTH=0 and
+    ShiftedTanh keep the generic set."""
+    import os
+    kw = dict(layers=[2, 100, 100, 100, 1], gamma=100.0, kinetic_coeff=1.0, pot_scale=1.0, dx=0.01)
+    x, flat, x_bc = _inputs(kw, 1500, scale=0.15)
+    pb = go.Problem(**kw)
+    P = go.param_count(kw["layers"])
+    a = make_engine(pb, flat, x, x_bc)                       # PATH_AUTO: padded, fused
+    b = make_engine(pb, flat, x, x_bc, path=gpe_pinn.PATH_GENERIC)
+    assert a.active_path == gpe_pinn.PATH_FUSED and b.active_path == gpe_pinn.PATH_GENERIC and a.n_params == b.n_params == P
+    assert "padded" in a.active_kernels and "padded" not in b.active_kernels and a.exchange_grad.numel() > b.exchange_grad.numel()
+    np.testing.assert_array_equal(a.get_params(), flat)
+    for k in range(40):
+        sa, sb = a.step(), b.step()
+        if k < 5:                # (two kernel sets, two summation orders: clipped Adam amplifies the rounding from there on)
+            assert abs(sa["loss"] - sb["loss"]) <= 1e-4 * (1 + k) * abs(sb["loss"]) and abs(sa["mu"] - sb["mu"]) <= 1e-4 * (1 + k) * abs(sb["mu"]), k
+        if k == 0:
+            assert H.rel_err(a.get_grad(), b.get_grad()) < 5e-5
+    pa = a.get_params()
+    assert np.abs(pa - flat).max() > 5e-3                                            # moved by ~40 lr
+    # had a padded weight moved, the network function would no longer be the caller's: evaluate the returned parameters on the other set
+    xt = torch.as_tensor(x, device="cuda")
+    ua = a.forward(xt).cpu().numpy()
+    b.set_params(pa)
+    assert H.rel_err(b.forward(xt).cpu().numpy(), ua) < 2e-6
+    m, v, step = a.get_adam_state()
+    assert step == 40 and m.shape == (P,) and np.abs(m).max() > 0
+    a.set_adam_state(m, v, step)
+    m2, v2, step2 = a.get_adam_state()
+    np.testing.assert_array_equal(m, m2); np.testing.assert_array_equal(v, v2)
+    a.close(); b.close()
+    os.environ["GPE_PAD_WIDTH"] = "0"
+    try:
+        c = make_engine(pb, flat, x, x_bc)
+        assert c.active_path == gpe_pinn.PATH_GENERIC
+        c.close()
+    finally:
+        os.environ.pop("GPE_PAD_WIDTH")
+    d = make_engine(go.Problem(**dict(kw, activation=1)), flat, x, x_bc)              # ShiftedTanh: a padded unit would output 1, not 0
+    assert d.active_path == gpe_pinn.PATH_GENERIC
+    d.close()
 
 
 # ---- native exchange: the engine's own RCCL communicator (world 1 on the one-GPU box: the same code path as N ranks) -----------
