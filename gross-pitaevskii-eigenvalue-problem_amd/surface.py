@@ -593,15 +593,24 @@ def _as_np(X):
 
 class _History:
     """Every epoch's record of one driver stage, kept on the returned model (`model.history[k]["loss" | "mu" | "lr" | ...]`): column
-    arrays instead of one dict per epoch (the 201-stage experiment records 400 000 epochs)."""
+    arrays instead of one dict per epoch (the 201-stage experiment records 400 000 epochs).  Built from a list of records or from the
+    engine's [n, fields] array."""
 
-    def __init__(self, rows):
-        self._keys = list(rows[0].keys()) if rows else []
-        self._cols = {k: np.array([r[k] for r in rows], dtype=np.float64) for k in self._keys}
-        self._n = len(rows)
+    def __init__(self, rows, keys=None):
+        if isinstance(rows, np.ndarray):
+            self._keys = list(keys)
+            self._cols = {k: rows[:, i] for i, k in enumerate(self._keys)}
+            self._n = rows.shape[0]
+        else:
+            self._keys = list(rows[0].keys()) if rows else []
+            self._cols = {k: np.array([r[k] for r in rows], dtype=np.float64) for k in self._keys}
+            self._n = len(rows)
 
     def __len__(self):
         return self._n
+
+    def __bool__(self):
+        return self._n > 0
 
     def __getitem__(self, k):
         if isinstance(k, str):
@@ -616,14 +625,15 @@ class _History:
         return (self[k] for k in range(self._n))
 
 
-def _history(eng: Engine, first: int, last: int, chunk: int = 8192):
-    out = []
+def _history(eng: Engine, first: int, last: int, chunk: int = 8192) -> "_History":
+    parts = []
     s = first
     while s <= last:
         n = min(chunk, last - s + 1)
-        out += eng.read_history(s, n)
+        parts.append(eng.read_history_array(s, n))
         s += n
-    return out
+    arr = np.concatenate(parts) if parts else np.zeros((0, len(Engine.HISTORY_FIELDS)))
+    return _History(arr, Engine.HISTORY_FIELDS)
 
 
 # ================================================================================================
@@ -681,7 +691,7 @@ def _refine_pretrain(model, mode, X_train, epochs=5000, lr=1e-3, verbose=False):
 
 
 def _refine_train(gamma_values, modes, p, X_train, lb, ub, layers, epochs, tol, perturb_const,
-                  potential_type="harmonic", lr=1e-5, verbose=True, pretrain="reference", chunk=500, _cls=None, _descending=False,
+                  potential_type="harmonic", lr=1e-5, verbose=True, pretrain="reference", chunk=128, _cls=None, _descending=False,
                   _make_model=None, _init_fn=None, _pot_over=None, _label="γ", **model_kw):
     """train_gpe_model of refine/harmonic_pinn_simulation.py:220-430 (PL-PINN, gamma continuation).
 
@@ -743,8 +753,9 @@ def _refine_train(gamma_values, modes, p, X_train, lb, ub, layers, epochs, tol, 
             model._bind_training_data(eng, X, X_dev, bpts)
             done = 0
             final_epoch = epochs
+            step_n = chunk
             while done < epochs:
-                n = min(chunk, epochs - done)
+                n = min(step_n, epochs - done)
                 eng.run(n)
                 done += n
                 stopped, stop_step = eng.stop_state()
@@ -753,21 +764,25 @@ def _refine_train(gamma_values, modes, p, X_train, lb, ub, layers, epochs, tol, 
                     if verbose:
                         print(f"Early stop at epoch {final_epoch}")
                     break
+                # epochs enqueued behind the stop epoch run frozen (parameters untouched) but still cost their launches: look more
+                # often once the loss is within a factor of four of the tolerance (the stop epoch itself stays exact either way)
+                if tol > 0 and chunk > 32:
+                    step_n = 32 if eng.read_scalars()["loss"] < 4.0 * tol else chunk
             n_rec = (final_epoch + 1) if final_epoch < epochs else epochs
             hist = _history(eng, 1, n_rec)
-            loss_history = [h["loss"] for i, h in enumerate(hist) if i % 10 == 0]            # :375-376
-            lambda_history = [h["mu"] for i, h in enumerate(hist) if i % 100 == 0]           # :379-380
-            constraint_history = [10.0 * h["bc"] + 20.0 * h["norm"] for i, h in enumerate(hist) if i % 100 == 0]
+            loss_history = hist["loss"][::10].tolist()                                       # :375-376
+            lambda_history = hist["mu"][::100].tolist()                                      # :379-380
+            constraint_history = (10.0 * hist["bc"][::100] + 20.0 * hist["norm"][::100]).tolist()
             if verbose:
-                for i, h in enumerate(hist):
-                    if i % 500 == 0:
-                        print(f"Epoch {i}, μ: {h['mu']:.4f}\nTotal Loss: {h['loss']:.6f}, PDE residual: {h['pde']:.6f}, "
-                              f"Constraints: {10.0 * h['bc'] + 20.0 * h['norm']:.6f}")
+                for i in range(0, len(hist), 500):
+                    h = hist[i]
+                    print(f"Epoch {i}, μ: {h['mu']:.4f}\nTotal Loss: {h['loss']:.6f}, PDE residual: {h['pde']:.6f}, "
+                          f"Constraints: {10.0 * h['bc'] + 20.0 * h['norm']:.6f}")
             model._pull()
-            model.history = _History(hist)                             # every epoch's record (the returned histories keep the reference's cadence)
+            model.history = hist                                       # every epoch's record (the returned histories keep the reference's cadence)
             final_mu = lambda_history[-1] if lambda_history else 0                           # :407 (quirk Q5)
             mu_logs.append((gamma, final_mu))
-            model.last_mu = hist[-1]["mu"] if hist else float("nan")
+            model.last_mu = float(hist["mu"][-1]) if len(hist) else float("nan")
             models_by_gamma[gamma] = model
             history_by_gamma[gamma] = {"loss": loss_history, "constraint": constraint_history, "lambda": lambda_history}
             epochs_by_gamma[gamma] = final_epoch
@@ -843,13 +858,13 @@ def _nb_train(gamma_values, powers, modes, X_train, lb, ub, layers, epochs, pote
                 eng.run(n)
                 done += n
             hist = _history(eng, 1, epochs)
-            lambda_history = [h["mu"] for i, h in enumerate(hist) if i % 100 == 0]           # c10:L106-108
+            lambda_history = hist["mu"][::100].tolist()                                      # c10:L106-108
             if verbose:
-                for i, h in enumerate(hist):
-                    if i % 500 == 0:
-                        print(f"Epoch {i}, Loss: {h['loss']:.6f}, μ: {h['mu']:.4f}")
+                for i in range(0, len(hist), 500):
+                    h = hist[i]
+                    print(f"Epoch {i}, Loss: {h['loss']:.6f}, μ: {h['mu']:.4f}")
             model._pull()
-            model.history = _History(hist)
+            model.history = hist
             final_mu = lambda_history[-1] if lambda_history else 0
             mu_logs.append((power, final_mu))
             models_by_power[power] = model
@@ -1116,13 +1131,12 @@ def _pinn2d_train(N_u=500, N_f=10000, layers=[2, 400, 400, 400, 1], epochs=1000,
         n = min(chunk, epochs - done)
         eng.run(n)
         done += n
-    hist = _history(eng, 1, epochs) if epochs > 0 else []
+    hist = _history(eng, 1, epochs) if epochs > 0 else _History([])
     if verbose:
-        for i, h in enumerate(hist):
-            if i % 400 == 0:
-                print(f"Epoch [{i}/{epochs}], Loss: {h['loss']:.6f}")
+        for i in range(0, len(hist), 400):
+            print(f"Epoch [{i}/{epochs}], Loss: {hist[i]['loss']:.6f}")
     model._pull()
-    model.history = _History(hist)
+    model.history = hist
     return model
 
 

@@ -51,7 +51,11 @@ def test_driver_history_container():
     assert [r["loss"] for r in h] == [1.0, 0.5] and list(h["mu"]) == [2.0, 2.5]
     with pytest.raises(IndexError):
         h[2]
-    assert len(_History([])) == 0
+    assert len(_History([])) == 0 and not _History([])
+    # ... and from the engine's [n, fields] array (no per-epoch objects: the 201-stage continuation reads 400 000 records)
+    import numpy as np
+    a = _History(np.array([[1.0, 2.0], [0.5, 2.5], [0.25, 3.0]]), ("loss", "mu"))
+    assert len(a) == 3 and a[2] == {"loss": 0.25, "mu": 3.0} and a["loss"][::2].tolist() == [1.0, 0.25] and [r["mu"] for r in a] == [2.0, 2.5, 3.0]
 
 
 def test_gpus_n_launches_n_ranks():
