@@ -382,7 +382,12 @@ def test_error_behaviour():
     with pytest.raises(ValueError):
         Engine(GPEConfig(layers=[4, 32, 32, 1]))
     with pytest.raises(ValueError):
-        Engine(GPEConfig(layers=[2, 96, 96, 1], path=gpe_pinn.PATH_FUSED))            # no whole-network kernel for this width
+        Engine(GPEConfig(layers=[2, 300, 300, 1], path=gpe_pinn.PATH_FUSED))          # no whole-network kernel for this width (> 256: not padded)
+    with pytest.raises(ValueError):
+        Engine(GPEConfig(layers=[2, 96, 96, 1], activation=gpe_pinn.ACT_TANH_PLUS1, path=gpe_pinn.PATH_FUSED))     # ShiftedTanh is not padded
+    e96 = Engine(GPEConfig(layers=[2, 96, 96, 1], path=gpe_pinn.PATH_FUSED))          # plain tanh: runs zero-padded to 128
+    assert e96.active_path == gpe_pinn.PATH_FUSED and e96.n_params == 2 * 96 + 96 + 96 * 96 + 96 + 96 + 1
+    e96.close()
     eng = Engine(GPEConfig(layers=[1, 32, 32, 1]))
     with pytest.raises(gpe_pinn.GPEError) as ei:
         eng.step()
