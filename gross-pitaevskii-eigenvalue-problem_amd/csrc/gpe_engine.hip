@@ -475,6 +475,7 @@ struct gpe_engine {
     int H = 0;                     // uniform hidden width (fused)
     bool wide = false;             // fused path: reverse pass by the wide kernel set (gpe_wide.h): H = 256 or 128
     bool wide_fwd = false;         // ... and the forward pass too (H = 256, H = 128 in 3D; H = 128 in 1D/2D keeps f_forward_coop: measured)
+    int64_t wide_min_tiles = 2048; // H = 128 in 1D/2D: batches below this many 16-point tiles take the single-launch cooperative reverse kernel
     int P = 0, Ppad = 0;
     // width padding: hidden widths without an MFMA kernel instance run zero-padded to the next width that has one.  P counts the
     // padded network (what the kernels, the optimiser and the gradient exchange see); the caller's flat vector has P_user entries
@@ -845,10 +846,19 @@ static bool seed_in_reverse(gpe_engine* e) {
            plain_terms(e) && e->cfg.w_sym == 0.f && e->main.C >= 3 && e->main.n > 0 && e->n_pde <= e->fuse_seed_max &&
            use_pipe(e, e->main.C) && bwd_kind(e, e->main) == 3;
 }
+// H = 128 in 1D / 2D has two reverse passes behind the cooperative forward kernel (same stored-activation format): one launch per map
+// (w_bwd_map: no spills, -3.6 % at 4 096 tiles) and the single cooperative launch (f_backward_coop<128>: fewer launches, -10 % at 256
+// tiles, -4 % at 1 024; profiles/r04/wide_small_batch_ab.txt).  The per-map form from wide_min_tiles tiles on (GPE_WIDE_MIN_TILES).
+static bool wide_reverse(gpe_engine* e, const Batch& b);
 static int bwd_kind(gpe_engine* e, const Batch& b) {
     if (coop_shape(e) && e->coop != 0 && (e->coop == 1 || (b.n + 15) / 16 <= e->coop_max_tiles)) return 3;
     if (e->H > 64 || !staged_batch(e, b)) return 0;
     return e->bwd_racc ? 2 : 0;
+}
+static bool wide_reverse(gpe_engine* e, const Batch& b) {
+    if (!e->wide) return false;
+    if (e->wide_fwd || e->H != 128 || e->nd.dim > 2) return true;              // H = 256, 3D: the wide set is the only one
+    return (b.n + 15) / 16 >= e->wide_min_tiles || bwd_kind(e, b) != 3;
 }
 // f_backward_pipe: two z and two X^T exchange buffers; taken when two workgroups per CU still fit
 static size_t pipe_lds(gpe_engine* e, int C) {
@@ -1110,7 +1120,7 @@ static int mlp_backward(gpe_engine* e, Batch& b, bool close = false, bool assign
         const bool mark = e->prof && (&b == &e->main);
         if (mark) prof_mark(e, 1, true);
         int nred = (int)grid;
-        if (e->wide) {
+        if (wide_reverse(e, b)) {
             if (!b.Z0) FAIL(e, GPE_ERR_STATE, "reverse pass on a forward-only batch");
             const int wr = wide_backward(wide_call(e, b));
             if (wr < 0) FAIL(e, GPE_ERR_INVALID, "wide kernel set: channels (%d,%d) / n_out %d not compiled", b.C, b.E, e->nd.n_out);
@@ -1341,7 +1351,8 @@ int gpe_active_kernels(gpe_engine* e, char* buf, size_t n) {
         if (e->wide_fwd) snprintf(f, sizeof f, "%s<%d,%d,%d,%d>", wide_forward_kernel(e->H), e->H, b.C, b.E, e->nd.n_out);
         else if (fwd_coop(e, b)) snprintf(f, sizeof f, "f_forward_coop<%d,%d,%d,%d,%d>", e->H, b.C, b.E, e->nd.n_out, maps > 5 ? 5 : maps);
         else snprintf(f, sizeof f, "f_forward<%d,%d,%d,%d,l2>", e->H, b.C, b.E, e->nd.n_out);
-        snprintf(r, sizeof r, "%d x w_bwd_map<%d,%d,%d,%d> (output layer fused into the top map)", maps, e->H, b.C, b.E, e->H / 128);
+        if (wide_reverse(e, const_cast<Batch&>(b))) snprintf(r, sizeof r, "%d x w_bwd_map<%d,%d,%d,%d> (output layer fused into the top map)", maps, e->H, b.C, b.E, e->H / 128);
+        else snprintf(r, sizeof r, "f_backward_coop<%d,%d,%d,%d,%d>", e->H, b.C, b.E, e->nd.n_out, maps > 5 ? 5 : maps);
     } else if (e->path == GPE_PATH_FUSED) {
         const bool fc = fwd_coop(e, b) && (e->H <= 64 || b.C <= 4);
         if (fc) snprintf(f, sizeof f, "f_forward_coop<%d,%d,%d,%d,%d>", e->H, b.C, b.E, e->nd.n_out, maps > 5 ? 5 : maps);
@@ -1561,6 +1572,7 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
     if (ok && e->path == GPE_PATH_FUSED) {
         e->nslab = (H >= 128) ? std::max(e->nslab_g, e->num_cu) : e->num_cu * 2;     // H = 128: 16 atomic slabs, or one per workgroup (cooperative)
         if (e->wide) wide_init();
+        { const char* envm = getenv("GPE_WIDE_MIN_TILES"); if (envm && atoll(envm) >= 0) e->wide_min_tiles = atoll(envm); }
         // WpkT is followed by the bf16 pieces of the same maps (3 x 2 bytes per weight; pack_weight_element, f_forward_b6)
         ok = alloc((void**)&e->Wpk, (size_t)(Lh - 1) * H * H * 4) && alloc((void**)&e->WpkT, (size_t)(Lh - 1) * H * H * (4 + 6 + 6)) &&
              alloc((void**)&e->gslab, (size_t)e->nslab * e->Ppad * 4);

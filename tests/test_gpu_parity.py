@@ -602,12 +602,12 @@ def test_side_stream_and_graph_replay_change_nothing(kw, N):
       {"GPE_COOP": "0", "GPE_STAGE_MIN_TILES": "1000000000"}]),
     (dict(layers=[2, 128, 128, 128, 1], gamma=50.0, dx=0.01), 777,
      [{"GPE_WIDE": "0", "GPE_COOP128": "1", "GPE_COOP_FWD128": "1"}, {"GPE_WIDE": "0", "GPE_COOP128": "0", "GPE_COOP_FWD128": "0"},
-      {"GPE_WIDE": "0", "GPE_COOP128": "1", "GPE_COOP_FWD128": "0"}, {}, {"GPE_WIDE": "1"}]),
+      {"GPE_WIDE": "0", "GPE_COOP128": "1", "GPE_COOP_FWD128": "0"}, {"GPE_WIDE_MIN_TILES": "0"}, {"GPE_WIDE": "1", "GPE_WIDE_MIN_TILES": "0"}]),
 ])
 def test_kernel_variants_agree(kw, N, envs):
     """The fused path has several kernels for the same two primitives -- cooperative (a workgroup per tile), per-wave-tile with
     LDS-staged weights + register-resident gradients, per-wave-tile unstaged with LDS-atomic gradients, global-atomic slabs for
-    H = 128, the wide set's per-map reverse kernels (default for H = 128) -- selected by shape and batch size.  One step from the same state must agree to fp32 round-off whichever runs."""
+    H = 128, the wide set's per-map reverse kernels (default for H = 128 from 2 048 tiles on; GPE_WIDE_MIN_TILES=0 takes them at any size) -- selected by shape and batch size.  One step from the same state must agree to fp32 round-off whichever runs."""
     scale = _scale(kw)
     ref = None
     seen = set()
@@ -637,7 +637,7 @@ def test_kernel_variants_agree(kw, N, envs):
     # every row ran a different kernel pair -- unless the suite itself runs under a forced switch (e.g. GPE_FWD_B6=1 GPE_BWD_B6=1 to
     # put the split-bf16 kernels through every test), which makes some rows coincide: then at least two distinct pairs
     import os
-    forced = [k for k in ("GPE_FWD_B6", "GPE_BWD_B6", "GPE_PIPE", "GPE_COOP", "GPE_WIDE", "GPE_COOP_FWD_MAX_TILES", "GPE_STAGE_MIN_TILES", "GPE_FUSE_SEED", "GPE_FUSE_HEAD")
+    forced = [k for k in ("GPE_FWD_B6", "GPE_BWD_B6", "GPE_PIPE", "GPE_COOP", "GPE_WIDE", "GPE_WIDE_MIN_TILES", "GPE_COOP_FWD_MAX_TILES", "GPE_STAGE_MIN_TILES", "GPE_FUSE_SEED", "GPE_FUSE_HEAD")
               if k in os.environ]
     if forced:
         assert len(seen) >= 2, f"forced {forced}: switches selected only {sorted(seen)}"
@@ -1153,6 +1153,29 @@ def test_stale_gradient_mode_is_the_one_step_delayed_trajectory(path):
         ref.step()
     assert np.abs(ref.get_params() - got).max() > 1e-4
     eng.close(); ref.close()
+
+
+@pytest.mark.parametrize("name", ["2d_128x5_cfg3", "2d_128x6_complex_cfg4", "1d_128x2", "2d_complex_72x3_pads_to_128", "2d_128x3_cfg3like"])
+def test_per_map_reverse_pass_of_h128_at_small_batches_matches_oracle(name):
+    """H = 128 in 1D / 2D: batches under 2 048 tiles take the single-launch cooperative reverse kernel by default (test_step_matches_oracle
+    covers that), larger ones the per-map kernels w_bwd_map<128> -- which GPE_WIDE_MIN_TILES=0 selects at any size, so that they too meet
+    the oracle on the small cases the oracle can do (their full-size runs are cross-checked against the generic set)."""
+    import os
+    kw, N, _ = CASES[name]
+    x, flat, x_bc = _inputs(kw, N, scale=_scale(kw))
+    pb = go.Problem(**kw)
+    osc, ograd, _ = go.full_loss_and_grad(pb, flat.astype(np.float64), x.astype(np.float64), x_bc.astype(np.float64))
+    old = os.environ.get("GPE_WIDE_MIN_TILES")
+    os.environ["GPE_WIDE_MIN_TILES"] = "0"
+    try:
+        eng = make_engine(pb, flat, x, x_bc)
+    finally:
+        os.environ.pop("GPE_WIDE_MIN_TILES", None) if old is None else os.environ.__setitem__("GPE_WIDE_MIN_TILES", old)
+    assert "w_bwd_map<128" in eng.active_kernels["bwd"], eng.active_kernels
+    sc = eng.step()
+    assert abs(sc["loss"] - osc["loss"]) <= 1e-4 * abs(osc["loss"]) and abs(sc["mu"] - osc["mu"]) <= 2e-5 * abs(osc["mu"])
+    assert H.rel_err(eng.get_grad(), ograd) < 5e-5
+    eng.close()
 
 
 def test_wide_set_output_layer_fused_or_separate_agree():
