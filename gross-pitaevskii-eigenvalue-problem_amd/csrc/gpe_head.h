@@ -102,7 +102,6 @@ __global__ __launch_bounds__(1024) void k_head_pde(Phys ph, float base_norm, Pts
                                                   const float* __restrict__ bc_target, float* __restrict__ Ob,
                                                   double* __restrict__ lsums) {
     constexpr int D = C - 1 - E;
-    __shared__ double red[16];
     double num = 0.0, den = 0.0, so[GPE_MAX_ORTH] = {0.0, 0.0, 0.0, 0.0};
     double rzk = 0.0, rzp = 0.0, rzi = 0.0, rzl = 0.0, bse = 0.0;
     // grid-stride: few workgroups, one double atomic each per sum (same-address atomics serialise at ~25 ns apiece)
@@ -188,24 +187,35 @@ __global__ __launch_bounds__(1024) void k_head_pde(Phys ph, float base_norm, Pts
             }
         }
     }
-    if (phys_needs_energy_sums(ph)) {
-        double t;
-        t = block_sum_256(rzk, red); if (threadIdx.x == 0) atomicAdd(&sums[S_RZ_K], t);
-        t = block_sum_256(rzp, red); if (threadIdx.x == 0) atomicAdd(&sums[S_RZ_P], t);
-        t = block_sum_256(rzi, red); if (threadIdx.x == 0) atomicAdd(&sums[S_RZ_I], t);
-        if (ph.complex_psi && ph.omega_rot != 0.f) { t = block_sum_256(rzl, red); if (threadIdx.x == 0) atomicAdd(&sums[S_RZ_L], t); }
-    }
-    if (n_pde < N) {
-        double t = block_sum_256(bse, red);
-        if (threadIdx.x == 0 && t != 0.0) atomicAdd(&lsums[LS_BC_SE2], t);
-    }
-    double r = block_sum_256(num, red);
-    if (threadIdx.x == 0) atomicAdd(&sums[S_NUM], r);
-    r = block_sum_256(den, red);
-    if (threadIdx.x == 0) atomicAdd(&sums[S_DEN], r);
-    for (int j = 0; j < ph.n_orth; ++j) {
-        r = block_sum_256(so[j], red);
-        if (threadIdx.x == 0) atomicAdd(&sums[S_ORTH0 + j], r);
+    // all partial sums of the workgroup in ONE pass: wave-level shuffles per value, one LDS exchange, one barrier pair (one pair per value
+    // before round 4: 6-8 of them were most of this kernel's time at the reference's batch sizes).  Same shuffle tree and the same wave
+    // order per value as block_sum_256, so every sum is bit-identical to the one-at-a-time form.
+    {
+        constexpr int K = 11;
+        __shared__ double redm[16 * K];
+        const bool en = phys_needs_energy_sums(ph), rot = en && ph.complex_psi && ph.omega_rot != 0.f;
+        double vals[K] = {num, den, bse, rzk, rzp, rzi, rzl, so[0], so[1], so[2], so[3]};
+        const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const bool on = k < 3 || (k < 6 && en) || (k == 6 && rot) || (k >= 7 && k - 7 < ph.n_orth);       // (uniform)
+            if (!on) continue;
+            double v = vals[k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+            if ((threadIdx.x & 63) == 0) redm[w * K + k] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < K) {
+            const int k = threadIdx.x;
+            const bool on = k < 2 || (k == 2 && n_pde < N) || (k >= 3 && k < 6 && en) || (k == 6 && rot) || (k >= 7 && k - 7 < ph.n_orth);
+            if (on) {
+                double r = 0.0;
+                for (int i2 = 0; i2 < nw; ++i2) r += redm[i2 * K + k];
+                double* dst = k == 0 ? &sums[S_NUM] : k == 1 ? &sums[S_DEN] : k == 2 ? &lsums[LS_BC_SE2] : k < 7 ? &sums[S_RZ_K + (k - 3)] : &sums[S_ORTH0 + (k - 7)];
+                if (k != 2 || r != 0.0) atomicAdd(dst, r);
+            }
+        }
     }
 }
 
