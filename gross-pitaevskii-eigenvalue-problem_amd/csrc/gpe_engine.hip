@@ -475,6 +475,7 @@ struct gpe_engine {
     int H = 0;                     // uniform hidden width (fused)
     bool wide = false;             // fused path: reverse pass by the wide kernel set (gpe_wide.h): H = 256 or 128
     bool wide_fwd = false;         // ... and the forward pass too (H = 256, H = 128 in 3D; H = 128 in 1D/2D keeps f_forward_coop: measured)
+    int64_t gen_min_chunk = 32;    // generic set, split-K weight gradient on the matrix cores: fewest points per wave (GPE_GEN_MIN_CHUNK; 256 before round 4)
     int64_t wide_min_tiles = 2048; // H = 128 in 1D/2D: batches below this many 16-point tiles take the single-launch cooperative reverse kernel
     int P = 0, Ppad = 0;
     // width padding: hidden widths without an MFMA kernel instance run zero-padded to the next width that has one.  P counts the
@@ -1085,10 +1086,11 @@ static int mlp_forward(gpe_engine* e, Batch& b, bool store) {
                 dim3 grid(cdiv(b.n, 16), nd.width[lin + 1] / 256);      // a block = one point tile x 256 outputs, jets shared through LDS
                 DISPATCH_FWD(b, hipLaunchKernelGGL((g_fwd_layer_mfma2<CC, EE>), grid, dim3(256), 0, e->stream, nd, lin, e->theta,
                                                     Sprev, Out, b.n, b.ld));
-            } else if (!Sskip && lin > 0 && nd.width[lin] % 64 == 0 && nd.width[lin + 1] % 64 == 0 && e->gen_mfma) {   // wide map: matrix cores
+            } else if (lin > 0 && nd.width[lin] % 64 == 0 && nd.width[lin + 1] % 64 == 0 && e->gen_mfma &&
+                       (!Sskip || nd.width[nd.skip[lin] + 1] == nd.width[lin + 1])) {   // wide map: matrix cores (round 4: residual blocks too)
                 dim3 grid(cdiv(cdiv(b.n, 16), 4), nd.width[lin + 1] / 64);
                 DISPATCH_FWD(b, hipLaunchKernelGGL((g_fwd_layer_mfma<CC, EE>), grid, dim3(256), 0, e->stream, nd, lin, e->theta,
-                                                    Sprev, Out, b.n, b.ld));
+                                                    Sprev, Out, b.n, b.ld, Sskip));
             } else if (nd.width[lin + 1] >= 64) {      // wide layer: 16 output features per thread
                 dim3 grid(cdiv(b.n, 256), cdiv(nd.width[lin + 1], G_FBW));
                 DISPATCH_FWD(b, hipLaunchKernelGGL((g_fwd_layer<CC, EE, G_FBW>), grid, dim3(256), 0, e->stream, nd, lin, e->theta,
@@ -1204,7 +1206,10 @@ static int mlp_backward(gpe_engine* e, Batch& b, bool close = false, bool assign
                 // wide hidden->hidden map: split-K GEMM over the points on the matrix cores
                 const int64_t want = (int64_t)e->num_cu * 16 / ((Ho / 64) * (K / 64)) + 1;          // chunks so that ~16 waves per CU exist
                 int64_t chunk = ((b.n + want - 1) / want + 15) / 16 * 16;
-                if (chunk < 256) chunk = 256;
+                // (a 64 x 64 map over 4 000 points -- the residual network of refine/box_to_gaussian at its own size -- ran as 16 waves of
+                // 256 points each, 100 us per map; measured per step at 256 / 128 / 64 / 32 points per wave: 637 / 447 / 348 / 312 us -- the atomics of a
+                // 64 x 64 block cost less than the serial walk)
+                if (chunk < e->gen_min_chunk) chunk = e->gen_min_chunk;
                 const int64_t nchunk = (b.n + chunk - 1) / chunk;
                 dim3 gw(Ho / 64, K / 64, (unsigned)((nchunk + 3) / 4));
                 DISPATCH_TRAIN(b, hipLaunchKernelGGL((g_bwd_weight_mfma<CC, EE>), gw, dim3(256), 0, e->stream, nd, lin, Sprev, Zb,
@@ -1654,6 +1659,7 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
         if (ok && e->path == GPE_PATH_FUSED) ok = alloc((void**)&e->gslab_bc, (size_t)e->nslab * e->Ppad * 4);
         const char* envm2 = getenv("GPE_GEN_MFMA");
         e->gen_mfma = !envm2 || atoi(envm2) != 0;
+        { const char* envc = getenv("GPE_GEN_MIN_CHUNK"); if (envc && atoll(envc) >= 16) e->gen_min_chunk = (atoll(envc) + 15) / 16 * 16; }
         const char* envm3 = getenv("GPE_GEN_MFMA2");
         e->gen_mfma2 = !envm3 || atoi(envm3) != 0;
 #ifndef GPE_FAST_BUILD

@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256, 1) void g_bwd_weight_mfma(NetDesc nd, int lin,
 template <int C, int E>
 __global__ __launch_bounds__(256) void g_fwd_layer_mfma(NetDesc nd, int lin, const float* __restrict__ theta,
                                                         const float* __restrict__ Sprev, float* __restrict__ Out, int64_t N,
-                                                        int64_t ld) {
+                                                        int64_t ld, const float* __restrict__ Sskip /* stored of hidden layer nd.skip[lin], or NULL */) {
     constexpr int D = C - 1 - E;
     const int K = nd.width[lin], Ho = nd.width[lin + 1];
     const int lane = threadIdx.x & 63, i = lane & 15, kq = lane >> 4, w = threadIdx.x >> 6;
@@ -383,14 +383,26 @@ __global__ __launch_bounds__(256) void g_fwd_layer_mfma(NetDesc nd, int lin, con
     }
     const bool last = (lin == nd.n_lin - 1);
     if (mp < N) {
+        const float sh = Sskip ? nd.shiftv[nd.skip[lin]] : 0.f;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = n0 + 16 * nt + 4 * kq + r;
+                float sk[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) sk[c] = 0.f;
+                if (Sskip) {      // residual block (refine/box_to_gaussian_pinn_simulation.py:58-62): z += activation jets of the block's input
+                    float zk[D > 0 ? D : 1], zkk[E > 0 ? E : 1];
+#pragma unroll
+                    for (int j = 0; j < D; ++j) zk[j] = Sskip[((int64_t)(1 + j) * Ho + n) * ld + mp];
+#pragma unroll
+                    for (int j = 0; j < E; ++j) zkk[j] = Sskip[((int64_t)(1 + D + j) * Ho + n) * ld + mp];
+                    act_from_stored<D, E>(Sskip[((int64_t)0 * Ho + n) * ld + mp], zk, zkk, sh, sk);
+                }
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
-                    float v = acc[nt][c][r];
+                    float v = acc[nt][c][r] + sk[c];
                     if (c == 0 && !last) v = gpe_tanh(v);
                     Out[((int64_t)c * Ho + n) * ld + mp] = v;
                 }
