@@ -1443,10 +1443,14 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
         int wmax = 0; bool uni = true;
         for (int i = 1; i < c.n_layers - 1; ++i) { wmax = std::max(wmax, c.layers[i]); uni = uni && c.layers[i] == c.layers[1]; }
         const bool native = uni && (wmax == 32 || wmax == 64 || wmax == 128 || wmax == 256);
-        if (!(envp && atoi(envp) == 0) && !native && c.path != GPE_PATH_GENERIC && c.net_kind == GPE_NET_MLP && c.activation == GPE_ACT_TANH &&
-            c.n_layers - 2 >= 2 && wmax <= 256) {
+        // (widths above 256 -- train_pinn's default [2,400,400,400,1], src/gross_pitaevskii_2D_minimal.py:278 -- have no whole-network kernel: they are
+        // padded to the next multiple of 256 so that the GENERIC set runs every hidden map on its 128 x 128-tile MFMA kernels instead of the VALU ones)
+        const bool big = wmax > 256 && wmax <= 1024 && !(uni && wmax % 256 == 0);
+        if (!(envp && atoi(envp) == 0) && (big || (!native && wmax <= 256)) && c.path != GPE_PATH_GENERIC && c.net_kind == GPE_NET_MLP &&
+            c.activation == GPE_ACT_TANH && c.n_layers - 2 >= 2) {
             // the smallest instantiated width that holds the widest layer and whose kernels take this depth (32 / 64: all weights in LDS)
-            int Hp = 0;
+            int Hp = big ? (int)round_up(wmax, 256) : 0;
+            if (!big)
             for (int h : {32, 64, 128, 256}) {
                 if (h < wmax) continue;
                 if (h <= 64) {

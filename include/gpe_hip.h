@@ -169,7 +169,7 @@ int gpe_active_kernels(gpe_engine* e, char* buf, size_t n);
 /* Hidden widths: the MFMA kernel sets exist for one width of 32, 64, 128 or 256 (>= 2 hidden layers).  A plain-tanh MLP with other hidden widths
  * <= 256 is run zero-padded to the next of those (exactly the same function and gradients; the padding stays zero under Adam); every call below
  * takes and returns the network AS GIVEN in gpe_config.layers.  Anything else (ShiftedTanh with odd widths, residual blocks, width > 256, one
- * hidden layer) runs on the generic layer-by-layer kernel set. */
+ * hidden layer) runs on the generic layer-by-layer kernel set -- plain-tanh widths above 256 padded to a multiple of 256 for its MFMA kernels. */
 int64_t gpe_param_count(const gpe_engine* e);
 int gpe_set_params(gpe_engine* e, const float* h_flat, size_t n);
 int gpe_get_params(gpe_engine* e, float* h_flat, size_t n);

@@ -1033,6 +1033,20 @@ def test_padded_hidden_widths_train_like_the_network_as_given():
     d = make_engine(go.Problem(**dict(kw, activation=1)), flat, x, x_bc)              # ShiftedTanh: a padded unit would output 1, not 0
     assert d.active_path == gpe_pinn.PATH_GENERIC
     d.close()
+    # widths above 256 (train_pinn's default [2,400,400,400,1]): padded to a multiple of 256 so that the GENERIC set runs its MFMA kernels
+    kw2 = dict(layers=[2, 400, 400, 400, 1], gamma=100.0, kinetic_coeff=1.0, pot_scale=1.0, dx=0.01)
+    x2, flat2, xb2 = _inputs(kw2, 700, scale=0.08)
+    pb2 = go.Problem(**kw2)
+    ea = make_engine(pb2, flat2, x2, xb2)
+    eb = make_engine(pb2, flat2, x2, xb2, path=gpe_pinn.PATH_GENERIC)
+    assert ea.active_path == gpe_pinn.PATH_GENERIC and "padded" in ea.active_kernels and "mfma" in ea.active_kernels["fwd"]
+    assert "padded" not in eb.active_kernels and ea.n_params == eb.n_params == go.param_count(kw2["layers"])
+    sa, sb = ea.step(), eb.step()
+    assert abs(sa["loss"] - sb["loss"]) <= 2e-5 * abs(sb["loss"]) and abs(sa["mu"] - sb["mu"]) <= 2e-5 * abs(sb["mu"])
+    assert H.rel_err(ea.get_grad(), eb.get_grad()) < 5e-5
+    osc, ograd, _ = go.full_loss_and_grad(pb2, flat2.astype(np.float64), x2.astype(np.float64), xb2.astype(np.float64))
+    assert abs(sa["loss"] - osc["loss"]) <= 1e-4 * abs(osc["loss"]) and H.rel_err(ea.get_grad(), ograd) < 5e-5
+    ea.close(); eb.close()
 
 
 # ---- native exchange: the engine's own RCCL communicator (world 1 on the one-GPU box: the same code path as N ranks) -----------
