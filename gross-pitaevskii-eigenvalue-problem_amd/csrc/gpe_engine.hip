@@ -483,6 +483,7 @@ struct gpe_engine {
     // and umap[i] is the padded index of its i-th entry.  Empty map: no padding, P_user == P.
     int P_user = 0;
     std::vector<int> umap;
+    std::vector<int> pad_bias;     // ShiftedTanh: biases of the padded units (held at -40: tanh = -1 exactly, so the unit outputs 0 with zero slope)
     int user_layers[GPE_MAX_LAYERS] = {0};
     float base_norm = 1.f;
     float *theta = nullptr, *am = nullptr, *av = nullptr, *grad = nullptr;   // grad: P + GT_COUNT
@@ -1436,7 +1437,9 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
     // the 2D scripts' own [2,100,100,100,1] (src/gross_pitaevskii_2D_minimal.py:377), ragged widths -- are run as the next such width with
     // zero rows / columns / biases in the padding.  A padded unit sees z = 0, gives tanh(0) = 0 with all jets 0, feeds zero outgoing weights
     // and so receives the gradient 0 exactly on every one of its weights: Adam leaves them at 0 and the network stays the caller's.
-    // (ShiftedTanh gives 1 there and a non-zero gradient on the outgoing weights: not padded.)  GPE_PAD_WIDTH=0 or GPE_PATH_GENERIC: as given.
+    // ShiftedTanh (tanh + 1) would give 1 there: its padded units get the bias -40 instead of 0 -- tanh(-40) = -1 exactly in fp32 (exp(-80) + 1 = 1),
+    // so the unit outputs exactly 0 with slope 1 - t^2 = 0, every gradient that touches it is 0 again, and the bias itself stays where it is.
+    // GPE_PAD_WIDTH=0 or GPE_PATH_GENERIC: as given.
     for (int i = 0; i < c.n_layers; ++i) e->user_layers[i] = c.layers[i];
     {
         const char* envp = getenv("GPE_PAD_WIDTH");
@@ -1447,7 +1450,7 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
         // padded to the next multiple of 256 so that the GENERIC set runs every hidden map on its 128 x 128-tile MFMA kernels instead of the VALU ones)
         const bool big = wmax > 256 && wmax <= 1024 && !(uni && wmax % 256 == 0);
         if (!(envp && atoi(envp) == 0) && (big || (!native && wmax <= 256)) && c.path != GPE_PATH_GENERIC && c.net_kind == GPE_NET_MLP &&
-            c.activation == GPE_ACT_TANH && c.n_layers - 2 >= 2) {
+            (c.activation == GPE_ACT_TANH || c.activation == GPE_ACT_TANH_PLUS1) && c.n_layers - 2 >= 2) {
             // the smallest instantiated width that holds the widest layer and whose kernels take this depth (32 / 64: all weights in LDS)
             int Hp = big ? (int)round_up(wmax, 256) : 0;
             if (!big)
@@ -1469,6 +1472,7 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
                 for (int o = 0; o < ou; ++o) for (int i = 0; i < iu; ++i) e->umap.push_back(offp + o * ip + i);
                 offp += ip * op;
                 for (int o = 0; o < ou; ++o) e->umap.push_back(offp + o);
+                if (c.activation == GPE_ACT_TANH_PLUS1 && j + 2 < c.n_layers) for (int o = ou; o < op; ++o) e->pad_bias.push_back(offp + o);
                 offp += op;
             }
             e->P_user = (int)e->umap.size();
@@ -1703,6 +1707,11 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
     fill_phys(e);
     int rc = reset_opt(e, c.lr);
     if (rc) return bail(rc);
+    if (!e->pad_bias.empty()) {                   // (the padding's biases are in place before the first gpe_set_params, too)
+        std::vector<float> pb(e->pad_bias.size(), -40.f);
+        for (size_t i = 0; i < pb.size(); ++i)
+            if (hipMemcpy(e->theta + e->pad_bias[i], &pb[i], sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { e->err = "hipMemcpy (padding)"; return bail(GPE_ERR_HIP); }
+    }
     *out = e;
     return GPE_OK;
 }
@@ -1739,6 +1748,7 @@ int gpe_synchronize(gpe_engine* e) {
 static int flat_to_device(gpe_engine* e, float* d_dst, const float* h_user) {
     if (e->umap.empty()) { HIPCHK(e, hipMemcpyAsync(d_dst, h_user, (size_t)e->P * 4, hipMemcpyHostToDevice, e->stream)); return GPE_OK; }
     std::vector<float> tmp((size_t)e->P, 0.f);
+    if (d_dst == e->theta) for (int i : e->pad_bias) tmp[i] = -40.f;         // (parameters only: the Adam moments of the padding are 0)
     for (int i = 0; i < e->P_user; ++i) tmp[e->umap[i]] = h_user[i];
     HIPCHK(e, hipMemcpyAsync(d_dst, tmp.data(), (size_t)e->P * 4, hipMemcpyHostToDevice, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));              // tmp dies with this frame

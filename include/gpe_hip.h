@@ -166,10 +166,11 @@ int gpe_active_path(const gpe_engine* e);
 int gpe_active_kernels(gpe_engine* e, char* buf, size_t n);
 
 /* ---- parameters: model.state_dict() / load_state_dict() (refine/...:299,909,953) --------------- */
-/* Hidden widths: the MFMA kernel sets exist for one width of 32, 64, 128 or 256 (>= 2 hidden layers).  A plain-tanh MLP with other hidden widths
- * <= 256 is run zero-padded to the next of those (exactly the same function and gradients; the padding stays zero under Adam); every call below
- * takes and returns the network AS GIVEN in gpe_config.layers.  Anything else (ShiftedTanh with odd widths, residual blocks, width > 256, one
- * hidden layer) runs on the generic layer-by-layer kernel set -- plain-tanh widths above 256 padded to a multiple of 256 for its MFMA kernels. */
+/* Hidden widths: the MFMA kernel sets exist for one width of 32, 64, 128 or 256 (>= 2 hidden layers).  An MLP with other hidden widths <= 256 is
+ * run padded to the next of those with units that output exactly 0 (zero weights; bias 0 for tanh, -40 for tanh + 1): the same function and
+ * gradients, and the padding does not move under Adam.  Every call below takes and returns the network AS GIVEN in gpe_config.layers.
+ * Residual blocks, widths above 256 and single-hidden-layer networks run on the generic layer-by-layer kernel set (widths above 256 padded to a
+ * multiple of 256 for its MFMA kernels). */
 int64_t gpe_param_count(const gpe_engine* e);
 int gpe_set_params(gpe_engine* e, const float* h_flat, size_t n);
 int gpe_get_params(gpe_engine* e, float* h_flat, size_t n);

@@ -120,6 +120,9 @@ CASES = {
     "2d_ragged_48_64_32": (dict(layers=[2, 48, 64, 32, 1], gamma=10.0, dx=0.01), 300, True),
     "3d_200x2_pads_to_256": (dict(layers=[3, 200, 200, 1], gamma=20.0, omega=(1.0, 1.4, 2.0), dx=0.01), 130, True),
     "1d_20x3_pads_to_32": (dict(layers=[1, 20, 20, 20, 1], gamma=2.0, base_mode=1, dx=0.03), 333, True),
+    "1d_shifted_tanh_48x3_pads_to_64": (dict(layers=[1, 48, 48, 48, 1], activation=1, kinetic_coeff=1.0, pot_scale=1.0, gamma=5.0, base_mode=2,
+                                             perturb_scale=0.05, dx=12 / 499), 500, True),
+    "2d_shifted_tanh_100x3_pads_to_128": (dict(layers=[2, 100, 100, 100, 1], activation=1, gamma=50.0, dx=0.01), 300, True),
     "2d_complex_72x3_pads_to_128": (dict(layers=[2, 72, 72, 72, 2], complex_psi=True, gamma=30.0, omega_rot=0.8, dx=0.02), 200, True),
     "1d_single_hidden": (dict(layers=[1, 64, 1], gamma=1.0, dx=0.01, base_mode=1), 50, False),
 }
@@ -383,8 +386,6 @@ def test_error_behaviour():
         Engine(GPEConfig(layers=[4, 32, 32, 1]))
     with pytest.raises(ValueError):
         Engine(GPEConfig(layers=[2, 300, 300, 1], path=gpe_pinn.PATH_FUSED))          # no whole-network kernel for this width (> 256: not padded)
-    with pytest.raises(ValueError):
-        Engine(GPEConfig(layers=[2, 96, 96, 1], activation=gpe_pinn.ACT_TANH_PLUS1, path=gpe_pinn.PATH_FUSED))     # ShiftedTanh is not padded
     e96 = Engine(GPEConfig(layers=[2, 96, 96, 1], path=gpe_pinn.PATH_FUSED))          # plain tanh: runs zero-padded to 128
     assert e96.active_path == gpe_pinn.PATH_FUSED and e96.n_params == 2 * 96 + 96 + 96 * 96 + 96 + 96 + 1
     e96.close()
@@ -992,8 +993,8 @@ def test_generic_kernel_variants_agree(kw, N):
 def test_padded_hidden_widths_train_like_the_network_as_given():
     """Width padding (hidden widths without an MFMA kernel instance run zero-padded on the fused path): the padded weights must stay exactly
     zero under Adam, i.e. 40 steps on the padded network are 40 steps on the caller's network -- compared with the generic set, which takes
-    the widths as given; parameters, gradient and Adam state cross the C ABI in the caller's layout and round-trip; GPE_PAD_WIDTH=0 and
-    ShiftedTanh keep the generic set."""
+    the widths as given; parameters, gradient and Adam state cross the C ABI in the caller's layout and round-trip; GPE_PAD_WIDTH=0 keeps
+    the generic set; ShiftedTanh networks are padded with units held at tanh = -1."""
     import os
     kw = dict(layers=[2, 100, 100, 100, 1], gamma=100.0, kinetic_coeff=1.0, pot_scale=1.0, dx=0.01)
     x, flat, x_bc = _inputs(kw, 1500, scale=0.15)
@@ -1030,9 +1031,21 @@ def test_padded_hidden_widths_train_like_the_network_as_given():
         c.close()
     finally:
         os.environ.pop("GPE_PAD_WIDTH")
-    d = make_engine(go.Problem(**dict(kw, activation=1)), flat, x, x_bc)              # ShiftedTanh: a padded unit would output 1, not 0
-    assert d.active_path == gpe_pinn.PATH_GENERIC
-    d.close()
+    # ShiftedTanh (tanh + 1): the padded units carry the bias -40, tanh = -1 exactly, output 0 with zero slope -- same contract
+    pbs = go.Problem(**dict(kw, activation=1))
+    d = make_engine(pbs, flat, x, x_bc)
+    g = make_engine(pbs, flat, x, x_bc, path=gpe_pinn.PATH_GENERIC)
+    assert d.active_path == gpe_pinn.PATH_FUSED and "padded" in d.active_kernels and g.active_path == gpe_pinn.PATH_GENERIC
+    for k in range(30):
+        sd, sg = d.step(), g.step()
+        if k < 4:
+            assert abs(sd["loss"] - sg["loss"]) <= 1e-4 * (1 + k) * abs(sg["loss"]), k
+        if k == 0:
+            assert H.rel_err(d.get_grad(), g.get_grad()) < 5e-5
+    pd = d.get_params()
+    g.set_params(pd)
+    assert H.rel_err(g.forward(xt).cpu().numpy(), d.forward(xt).cpu().numpy()) < 1e-5 and np.abs(pd - flat).max() > 5e-3    # (a moved padding unit would show at 1e-2)
+    d.close(); g.close()
     # widths above 256 (train_pinn's default [2,400,400,400,1]): padded to a multiple of 256 so that the GENERIC set runs its MFMA kernels
     kw2 = dict(layers=[2, 400, 400, 400, 1], gamma=100.0, kinetic_coeff=1.0, pot_scale=1.0, dx=0.01)
     x2, flat2, xb2 = _inputs(kw2, 700, scale=0.08)
