@@ -709,6 +709,7 @@ static unsigned fused_grid(gpe_engine* e, int64_t n, int waves_per_block, int bl
 static bool fwd_coop(gpe_engine* e, const Batch& b) {
     if (!coop_shape(e) || e->coop == 0) return false;
     if (e->H == 128) return e->coop_fwd128;           // wide layers: the cooperative forward wins at every size (measured)
+    if (e->nd.n_lin - 2 > 3) return true;             // four / five maps at H <= 64: the only whole-network forward kernel that holds their weights
     return (b.n + 15) / 16 <= e->coop_fwd_max_tiles;
 }
 #define HEAD_SLOTS 512
@@ -721,7 +722,7 @@ static bool plain_terms(const gpe_engine* e) {
 // the head too, k_head_pde is not launched and the step sums are added in a fixed order
 // problem class whose head the forward kernels can run (head_point_real): real psi, no orthogonality / Riesz / symmetry terms
 static bool head_class(gpe_engine* e) {
-    return e->fuse_head && e->head_slots && e->path == GPE_PATH_FUSED && !e->wide && e->H <= 64 && e->nd.n_out == 1 && !e->cfg.complex_psi &&
+    return e->fuse_head && e->head_slots && e->path == GPE_PATH_FUSED && !e->wide && e->H <= 64 && e->nd.n_lin - 2 <= 3 && e->nd.n_out == 1 && !e->cfg.complex_psi &&
            e->ph.n_orth == 0 && plain_terms(e) && e->cfg.w_sym == 0.f && e->main.C >= 3 && e->main.n > 0;
 }
 // ... by the cooperative forward kernel (small batches; the reverse kernel forms the seeds and adds the triples)
@@ -757,11 +758,11 @@ static void launch_fcoop_no(gpe_engine* e, Batch& b, unsigned grid, size_t lds, 
         case 2: hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, NO, 2>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
         case 3: hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, NO, 3>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
         case 4:
-            if constexpr (HH == 128)
+            if constexpr (HH == 128 || NO == 1)
                 hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, NO, 4>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS);
             break;
         default:
-            if constexpr (HH == 128)
+            if constexpr (HH == 128 || NO == 1)
                 hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, NO, 5>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS);
             break;
     }
@@ -836,7 +837,10 @@ static void launch_f_forward(gpe_engine* e, Batch& b, unsigned grid, int store) 
 static bool coop_shape(gpe_engine* e) {
     if (e->path != GPE_PATH_FUSED) return false;
     const int maps = e->nd.n_lin - 2;                 // hidden -> hidden maps
-    if (e->H <= 64) return maps >= 1 && maps <= 3;
+    // H <= 64: one to three maps on the pipelined / cooperative kernels; round 4: FOUR and FIVE maps (real psi) on the cooperative ones too -- the
+    // per-wave-tile kernels cannot hold a fourth map's weight gradient in registers, nor its weights in 64 KB of LDS, and ran such networks 2.4-3x
+    // slower per FLOP (profiles/r04/deep_h64_networks.txt)
+    if (e->H <= 64) return maps >= 1 && maps <= (e->nd.n_out == 1 ? 5 : 3);
     return e->H == 128 && maps >= 1 && maps <= 5 && e->nd.dim <= 2 && e->coop128;    // 8 waves per workgroup, weights streamed from L2
 }
 static int bwd_kind(gpe_engine* e, const Batch& b);
@@ -853,7 +857,7 @@ static bool seed_in_reverse(gpe_engine* e) {
 // tiles, -4 % at 1 024; profiles/r04/wide_small_batch_ab.txt).  The per-map form from wide_min_tiles tiles on (GPE_WIDE_MIN_TILES).
 static bool wide_reverse(gpe_engine* e, const Batch& b);
 static int bwd_kind(gpe_engine* e, const Batch& b) {
-    if (coop_shape(e) && e->coop != 0 && (e->coop == 1 || (b.n + 15) / 16 <= e->coop_max_tiles)) return 3;
+    if (coop_shape(e) && e->coop != 0 && (e->coop == 1 || (b.n + 15) / 16 <= e->coop_max_tiles || (e->H <= 64 && e->nd.n_lin - 2 > 3))) return 3;
     if (e->H > 64 || !staged_batch(e, b)) return 0;
     return e->bwd_racc ? 2 : 0;
 }
@@ -895,7 +899,7 @@ template <int HH, int CC, int EE, int NO>
 static void launch_coop_no(gpe_engine* e, Batch& b, unsigned grid, size_t lds) {
 #define CARGS e->nd, e->theta, e->WpkT, b.pts, b.stored, b.Ob, e->gslab, b.n, b.ld, e->Ppad
     if constexpr (HH <= 64) {
-        if (e->bwd_b6) {
+        if (e->bwd_b6 && e->nd.n_lin - 2 <= 3) {
             switch (e->nd.n_lin - 2) {
                 case 1: hipLaunchKernelGGL((f_backward_coop<HH, CC, EE, NO, 1, true>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
                 case 2: hipLaunchKernelGGL((f_backward_coop<HH, CC, EE, NO, 2, true>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
@@ -933,11 +937,11 @@ static void launch_coop_no(gpe_engine* e, Batch& b, unsigned grid, size_t lds) {
         case 2: hipLaunchKernelGGL((f_backward_coop<HH, CC, EE, NO, 2>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
         case 3: hipLaunchKernelGGL((f_backward_coop<HH, CC, EE, NO, 3>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
         case 4:
-            if constexpr (HH == 128)
+            if constexpr (HH == 128 || NO == 1)
                 hipLaunchKernelGGL((f_backward_coop<HH, CC, EE, NO, 4>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS);
             break;
         default:
-            if constexpr (HH == 128)
+            if constexpr (HH == 128 || NO == 1)
                 hipLaunchKernelGGL((f_backward_coop<HH, CC, EE, NO, 5>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS);
             break;
     }
@@ -1631,6 +1635,10 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
     (void)hipFuncSetAttribute((const void*)f_backward_coop<HH, CC, EE, NO, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
     (void)hipFuncSetAttribute((const void*)f_backward_coop<HH, CC, EE, NO, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
     (void)hipFuncSetAttribute((const void*)f_backward_coop<HH, CC, EE, NO, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
+    if constexpr (NO == 1) {                                                                                                        \
+        (void)hipFuncSetAttribute((const void*)f_backward_coop<HH, CC, EE, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
+        (void)hipFuncSetAttribute((const void*)f_backward_coop<HH, CC, EE, 1, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
+    }                                                                                                                               \
     set_pipe_lds<HH, CC, EE, NO>(lds_b);                                                                                        \
     (void)hipFuncSetAttribute((const void*)f_backward_coop<HH, CC, EE, NO, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
     (void)hipFuncSetAttribute((const void*)f_backward_coop<HH, CC, EE, NO, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \

@@ -113,6 +113,14 @@ CASES = {
     "1d_residual_64x2blocks": (dict(layers=[1, 64, 64, 64, 1], net_kind=go.NET_RESIDUAL, activation=1, kinetic_coeff=1.0,
                                     potential=go.POT_GAUSSIAN, pot_a=0.5, gamma=3.0, p=4, base_mode=1, perturb_scale=0.05, dx=0.03), 333, False),
     "2d_residual_128x3blocks": (dict(layers=[2, 128, 128, 128, 128, 1], net_kind=go.NET_RESIDUAL, gamma=20.0, dx=0.01), 300, False),
+    # four and five hidden -> hidden maps at H <= 64 (round 4: on the cooperative whole-network kernels; the per-wave-tile kernels hold three)
+    "2d_64x5_four_maps": (dict(layers=[2, 64, 64, 64, 64, 64, 1], gamma=100.0, dx=0.01), 777, True),
+    "1d_64x6_five_maps": (dict(layers=[1, 64, 64, 64, 64, 64, 64, 1], gamma=5.0, base_mode=1, dx=12 / 499), 500, True),
+    "1d_shifted_tanh_64x5_four_maps": (dict(layers=[1, 64, 64, 64, 64, 64, 1], activation=1, kinetic_coeff=1.0, pot_scale=1.0, gamma=5.0, base_mode=0,
+                                            perturb_scale=0.05, dx=12 / 299), 300, True),
+    "3d_64x5_four_maps": (dict(layers=[3, 64, 64, 64, 64, 64, 1], gamma=20.0, omega=(1.0, 1.4, 2.0), dx=0.01), 300, True),
+    "2d_32x6_five_maps_sym": (dict(layers=[2, 32, 32, 32, 32, 32, 32, 1], gamma=10.0, dx=0.01), 401, True),
+    "2d_48x5_pads_to_64_four_maps": (dict(layers=[2, 48, 48, 48, 48, 48, 1], gamma=10.0, dx=0.01), 300, True),
     # hidden widths without an MFMA kernel instance: the fused path runs them zero-padded to the next instantiated width (plain tanh only);
     # the generic set takes them as given
     "2d_100x2_odd_width": (dict(layers=[2, 100, 100, 1], gamma=1.0, dx=0.01), 77, True),
@@ -222,6 +230,26 @@ def test_fused_and_generic_agree_full_size():
     assert abs(a["mu"] - b["mu"]) < 1e-5 * abs(a["mu"])
     assert abs(a["loss"] - b["loss"]) < 1e-4 * abs(a["loss"])
     assert H.rel_err(gb, ga) < 2e-4
+
+
+def test_deep_h64_network_on_the_cooperative_kernels_at_a_large_batch():
+    """[2,64x5,1] (four hidden -> hidden maps) at 300 001 points: cooperative whole-network kernels at a size where three-map networks take
+    the per-wave-tile kernels -- against the generic set (independent implementation) and the fp64 oracle."""
+    kw = dict(layers=[2, 64, 64, 64, 64, 64, 1], gamma=50.0, dx=0.01)
+    N = 300001
+    x, flat, x_bc = _inputs(kw, N, scale=_scale(kw))
+    pb = go.Problem(**kw)
+    a = make_engine(pb, flat, x, x_bc)
+    k = a.active_kernels
+    assert a.active_path == gpe_pinn.PATH_FUSED and k["fwd"].startswith("f_forward_coop<64") and k["bwd"].startswith("f_backward_coop<64"), k
+    sa = a.step(); ga = a.get_grad(); a.close()
+    b = make_engine(pb, flat, x, x_bc, path=gpe_pinn.PATH_GENERIC)
+    sb = b.step(); gb = b.get_grad(); b.close()
+    assert abs(sa["loss"] - sb["loss"]) <= 1e-4 * abs(sb["loss"]) and abs(sa["mu"] - sb["mu"]) <= 2e-5 * abs(sb["mu"])
+    assert H.rel_err(ga, gb) < 2e-4
+    osc, ograd = go.sharded_loss_and_grad(pb, flat.astype(np.float64), x.astype(np.float64), x_bc.astype(np.float64), chunk=65536, threads=8)
+    assert abs(sa["loss"] - osc["loss"]) <= 1e-4 * abs(osc["loss"]) and abs(sa["mu"] - osc["mu"]) <= 2e-5 * abs(osc["mu"])
+    assert H.rel_err(ga, ograd) < 5e-5
 
 
 @pytest.mark.parametrize("extra", [{}, dict(kinetic_coeff=1.0, pot_scale=1.0, w_norm=0.0, w_riesz=0.05, riesz_kind=go.RIESZ_SUM,
