@@ -709,7 +709,7 @@ static unsigned fused_grid(gpe_engine* e, int64_t n, int waves_per_block, int bl
 static bool fwd_coop(gpe_engine* e, const Batch& b) {
     if (!coop_shape(e) || e->coop == 0) return false;
     if (e->H == 128) return e->coop_fwd128;           // wide layers: the cooperative forward wins at every size (measured)
-    if (e->nd.n_lin - 2 > 3) return true;             // four / five maps at H <= 64: the only whole-network forward kernel that holds their weights
+    if (e->nd.n_lin - 2 > 3 || e->cfg.net_kind == GPE_NET_RESIDUAL) return true;    // four / five maps at H <= 64, residual blocks: only the cooperative kernels take them
     return (b.n + 15) / 16 <= e->coop_fwd_max_tiles;
 }
 #define HEAD_SLOTS 512
@@ -722,7 +722,7 @@ static bool plain_terms(const gpe_engine* e) {
 // the head too, k_head_pde is not launched and the step sums are added in a fixed order
 // problem class whose head the forward kernels can run (head_point_real): real psi, no orthogonality / Riesz / symmetry terms
 static bool head_class(gpe_engine* e) {
-    return e->fuse_head && e->head_slots && e->path == GPE_PATH_FUSED && !e->wide && e->H <= 64 && e->nd.n_lin - 2 <= 3 && e->nd.n_out == 1 && !e->cfg.complex_psi &&
+    return e->fuse_head && e->head_slots && e->path == GPE_PATH_FUSED && !e->wide && e->H <= 64 && e->nd.n_lin - 2 <= 3 && e->cfg.net_kind == GPE_NET_MLP && e->nd.n_out == 1 && !e->cfg.complex_psi &&
            e->ph.n_orth == 0 && plain_terms(e) && e->cfg.w_sym == 0.f && e->main.C >= 3 && e->main.n > 0;
 }
 // ... by the cooperative forward kernel (small batches; the reverse kernel forms the seeds and adds the triples)
@@ -753,6 +753,13 @@ static void launch_fcoop_no(gpe_engine* e, Batch& b, unsigned grid, size_t lds, 
 #undef CARGS
     const HeadArgs nohead{};
 #define CARGS e->nd, e->theta, e->Wpk, b.pts, b.stored, b.O, b.n, b.ld, store, nohead
+    if constexpr (HH <= 64 && NO == 1) {
+        if (e->cfg.net_kind == GPE_NET_RESIDUAL) {        // one or two residual blocks (checked at gpe_create)
+            if (e->nd.n_lin - 2 == 2) hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, 1, 2, false, true>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS);
+            else hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, 1, 4, false, true>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS);
+            return;
+        }
+    }
     switch (e->nd.n_lin - 2) {
         case 1: hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, NO, 1>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
         case 2: hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, NO, 2>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
@@ -857,7 +864,7 @@ static bool seed_in_reverse(gpe_engine* e) {
 // tiles, -4 % at 1 024; profiles/r04/wide_small_batch_ab.txt).  The per-map form from wide_min_tiles tiles on (GPE_WIDE_MIN_TILES).
 static bool wide_reverse(gpe_engine* e, const Batch& b);
 static int bwd_kind(gpe_engine* e, const Batch& b) {
-    if (coop_shape(e) && e->coop != 0 && (e->coop == 1 || (b.n + 15) / 16 <= e->coop_max_tiles || (e->H <= 64 && e->nd.n_lin - 2 > 3))) return 3;
+    if (coop_shape(e) && e->coop != 0 && (e->coop == 1 || (b.n + 15) / 16 <= e->coop_max_tiles || (e->H <= 64 && (e->nd.n_lin - 2 > 3 || e->cfg.net_kind == GPE_NET_RESIDUAL)))) return 3;
     if (e->H > 64 || !staged_batch(e, b)) return 0;
     return e->bwd_racc ? 2 : 0;
 }
@@ -873,7 +880,7 @@ static size_t pipe_lds(gpe_engine* e, int C) {
     return (n_gsm + 4 * (size_t)H) * sizeof(float) + fused_small_bytes(e) + (size_t)4 * C * NT * 256 * sizeof(float);
 }
 static bool use_pipe(gpe_engine* e, int C) {
-    return e->bwd_pipe && !e->bwd_b6 && e->H <= 64 && e->nd.n_lin - 2 >= 1 && e->nd.n_lin - 2 <= 3 && 2 * (pipe_lds(e, C) + 1024) <= (size_t)160 * 1024;
+    return e->bwd_pipe && !e->bwd_b6 && e->H <= 64 && e->cfg.net_kind == GPE_NET_MLP && e->nd.n_lin - 2 >= 1 && e->nd.n_lin - 2 <= 3 && 2 * (pipe_lds(e, C) + 1024) <= (size_t)160 * 1024;
 }
 static size_t coop_lds(gpe_engine* e, int C) {
     if (use_pipe(e, C)) return pipe_lds(e, C);
@@ -899,7 +906,7 @@ template <int HH, int CC, int EE, int NO>
 static void launch_coop_no(gpe_engine* e, Batch& b, unsigned grid, size_t lds) {
 #define CARGS e->nd, e->theta, e->WpkT, b.pts, b.stored, b.Ob, e->gslab, b.n, b.ld, e->Ppad
     if constexpr (HH <= 64) {
-        if (e->bwd_b6 && e->nd.n_lin - 2 <= 3) {
+        if (e->bwd_b6 && e->nd.n_lin - 2 <= 3 && e->cfg.net_kind == GPE_NET_MLP) {
             switch (e->nd.n_lin - 2) {
                 case 1: hipLaunchKernelGGL((f_backward_coop<HH, CC, EE, NO, 1, true>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
                 case 2: hipLaunchKernelGGL((f_backward_coop<HH, CC, EE, NO, 2, true>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS); break;
@@ -929,6 +936,13 @@ static void launch_coop_no(gpe_engine* e, Batch& b, unsigned grid, size_t lds) {
                 case 2: hipLaunchKernelGGL((f_backward_pipe<HH, CC, EE, NO, 2>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS, none); break;
                 default: hipLaunchKernelGGL((f_backward_pipe<HH, CC, EE, NO, 3>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS, none); break;
             }
+            return;
+        }
+    }
+    if constexpr (HH <= 64 && NO == 1) {
+        if (e->cfg.net_kind == GPE_NET_RESIDUAL) {
+            if (e->nd.n_lin - 2 == 2) hipLaunchKernelGGL((f_backward_coop<HH, CC, EE, 1, 2, false, true>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS);
+            else hipLaunchKernelGGL((f_backward_coop<HH, CC, EE, 1, 4, false, true>), dim3(grid), dim3(HH * 4), lds, e->stream, CARGS);
             return;
         }
     }
@@ -1515,10 +1529,15 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
     bool uniform = true;
     for (int i = 2; i < c.n_layers - 1; ++i) uniform = uniform && (c.layers[i] == c.layers[1]);
     const int H = c.layers[1];
-    const int Lh = c.n_layers - 2;
-    size_t lds_need = ((size_t)e->Ppad + (size_t)(8 + c.n_layers + 2) * c.layers[1] + 8 + 4 * (dim + 2) * F_TILE) * sizeof(float);
-    if (c.net_kind == GPE_NET_RESIDUAL) uniform = false;                        // residual blocks: generic set only
+    const int Lh = nd.n_lin - 1;                                                 // hidden layers (an MLP's n_layers - 2; a residual network's 2 blocks + 1)
+    size_t lds_need = ((size_t)e->Ppad + (size_t)(8 + nd.n_lin + 3) * c.layers[1] + 8 + 4 * (dim + 2) * F_TILE) * sizeof(float);
+    // residual blocks (refine/box_to_gaussian_pinn_simulation.py): round 4 -- one or two blocks of width 32 / 64, real psi, on the cooperative
+    // whole-network kernels (f_forward_coop / f_backward_coop <..., RES>); everything else on the generic set
+    const bool residual = c.net_kind == GPE_NET_RESIDUAL;
+    if (residual && !((H == 32 || H == 64) && no == 1 && (nd.n_lin - 2 == 2 || nd.n_lin - 2 == 4))) uniform = false;
+    { const char* envr = getenv("GPE_RES_FUSED"); if (residual && envr && atoi(envr) == 0) uniform = false; }
     bool fused_ok = uniform && (H == 32 || H == 64) && Lh >= 2 && lds_need <= 160 * 1024;
+    if (residual && (H == 128 || H == 256)) uniform = false;                    // (no residual form of the 8-wave kernels)
     if (uniform && H == 128 && Lh >= 2 && dim <= 2) fused_ok = true;          // cooperative kernels, weights streamed from L2
     // wide kernel set: H = 256 and 3D H = 128 entirely; 1D/2D H = 128: its per-map reverse kernels (no register spills, -5..7 % against
     // f_backward_coop<128>) behind the cooperative forward kernel (7 % faster than w_forward there) -- same stored-activation format.
@@ -1636,6 +1655,8 @@ int gpe_create(const gpe_config* cfg, int device, void* hip_stream, gpe_engine**
     (void)hipFuncSetAttribute((const void*)f_backward_coop<HH, CC, EE, NO, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
     (void)hipFuncSetAttribute((const void*)f_backward_coop<HH, CC, EE, NO, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
     if constexpr (NO == 1) {                                                                                                        \
+        (void)hipFuncSetAttribute((const void*)f_backward_coop<HH, CC, EE, 1, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
+        (void)hipFuncSetAttribute((const void*)f_backward_coop<HH, CC, EE, 1, 4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
         (void)hipFuncSetAttribute((const void*)f_backward_coop<HH, CC, EE, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
         (void)hipFuncSetAttribute((const void*)f_backward_coop<HH, CC, EE, 1, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b); \
     }                                                                                                                               \

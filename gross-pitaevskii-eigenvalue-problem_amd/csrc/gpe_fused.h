@@ -789,12 +789,17 @@ __global__ __launch_bounds__((NHH > 0 ? 256 : (WLDS ? 512 : 256)), ((NHH > 0 || 
 // of its tiles' rows -- u, H u, boundary seeds (head_point_real, gpe_head.h) -- and leaves ONE (num, den, bse) triple per workgroup in
 // ha.slots; k_head_pde is not launched, and the sums become reproducible bit for bit (no atomics: the reverse kernel adds the
 // triples in index order).
-template <int H, int C, int E, int NOUT, int NHH, bool HEADF = false>
+// RES (round 4): the residual-block network of refine/box_to_gaussian_pinn_simulation.py:52-63,100-130 -- hidden layer 0 = act(lin0 x), then
+// NHH / 2 blocks  tanh(lin2(tanh(lin1 a)) + a): the even hidden layers 2, 4, .. add the activation jets of the hidden layer two below (the block
+// input) to their pre-activation jets.  A wave's slice of the block input is its own output of two layers ago: kept in registers (C x 4).
+// Plain tanh inside the blocks, `shift` on layer 0 only.
+template <int H, int C, int E, int NOUT, int NHH, bool HEADF = false, bool RES = false>
 __global__ __launch_bounds__(H * 4, 2) void f_forward_coop(NetDesc nd, const float* __restrict__ theta,
                                                            const float* __restrict__ Wpk, Pts x,
                                                            float* __restrict__ stored, float* __restrict__ O, int64_t N,
                                                            int64_t ld, int store_acts, HeadArgs ha) {
     static_assert(!HEADF || NOUT == 1, "head in the forward kernel: real psi");
+    static_assert(!RES || ((NHH & 1) == 0 && !HEADF && H <= 64), "residual blocks: two maps each");
     constexpr int D = C - 1 - E, NT = H / 16, NTHR = 64 * NT;
     constexpr int L = NHH + 1;
     extern __shared__ __attribute__((aligned(16))) float lds_c[];
@@ -830,6 +835,11 @@ __global__ __launch_bounds__(H * 4, 2) void f_forward_coop(NetDesc nd, const flo
             f32x4 st[C];
             layer0_st<H, C, E>(w0s, xv, w, q, st);
             act_from_stored<D, E>(st[0], st + 1, st + 1 + D, shift, a);          // layer0_st leaves the second-order channels zero
+        }
+        f32x4 asave[RES ? C : 1];                                                   // RES: this wave's slice of the current block's input
+        if constexpr (RES) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) asave[c] = a[c];
         }
 #pragma unroll
         for (int j = 1; j <= NHH; ++j) {
@@ -882,8 +892,20 @@ __global__ __launch_bounds__(H * 4, 2) void f_forward_coop(NetDesc nd, const flo
             }
 
             if constexpr (H == 128 && GPE_FCOOP_ALT_PRIO) __builtin_amdgcn_s_setprio(0);
+            if constexpr (RES) {
+                if ((j & 1) == 0) {                                                 // second map of a block: + the block input
+#pragma unroll
+                    for (int c = 0; c < C; ++c) acc[c] += asave[c];
+                }
+            }
             const f32x4 tt = gpe_tanh(acc[0]);
-            act_from_stored<D, E>(tt, acc + 1, acc + 1 + D, shift, a);
+            act_from_stored<D, E>(tt, acc + 1, acc + 1 + D, RES ? 0.f : shift, a);
+            if constexpr (RES) {
+                if ((j & 1) == 0) {                                                 // ... whose output is the next block's input
+#pragma unroll
+                    for (int c = 0; c < C; ++c) asave[c] = a[c];
+                }
+            }
             if (store_acts) {      // through a per-(tile, layer) buffer descriptor: no 64-bit VALU address arithmetic per store
                 const buf_t sb = buf_make(stored + ((size_t)tile * (L - 1) + (j - 1)) * (C * NT * 256), (unsigned)(C * NT * 256 * sizeof(float)));
                 const int wu = __builtin_amdgcn_readfirstlane(w);
@@ -960,7 +982,9 @@ __global__ __launch_bounds__(H * 4, 2) void f_forward_coop(NetDesc nd, const flo
 // f_forward_b6): every wave publishes the PIECES of its zbar fragment (24 B instead of 16 B per four values), the W^T pieces come
 // from L2 (six 1 KiB loads per map, requested before the barrier).  The weight-gradient products contract over the 16 POINTS of a
 // tile -- half a K = 32 slab -- and stay on the fp32 instruction.
-template <int H, int C, int E, int NOUT, int NHH, bool B6 = false>
+// RES (round 4): residual-block network (see f_forward_coop).  zbar of an even hidden layer j >= 2 also reaches the adjoint of the block input,
+// hidden layer j - 2: the wave keeps its slice of zbar_j (C x 4 registers) and adds it to  W_{j-1}^T zbar_{j-1}  one map later.
+template <int H, int C, int E, int NOUT, int NHH, bool B6 = false, bool RES = false>
 __global__ __launch_bounds__(H * 4, 2) void f_backward_coop(NetDesc nd, const float* __restrict__ theta,
                                                             const float* __restrict__ WpkT, Pts x,
                                                             const float* __restrict__ stored, const float* __restrict__ Ob,
@@ -1062,7 +1086,7 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_coop(NetDesc nd, const fl
             for (int o = 0; o < NOUT; ++o) wo[o] = *reinterpret_cast<const f32x4*>(&Wo[o * H + 16 * w + 4 * q]);
             {
                 f32x4 a4[C], ab4[C];
-                act_from_stored<D, E>(st[0], st + 1, st + 1 + D, shift, a4);
+                act_from_stored<D, E>(st[0], st + 1, st + 1 + D, RES ? 0.f : shift, a4);        // (RES: plain tanh above layer 0; L - 1 >= 1)
 #pragma unroll
                 for (int o = 0; o < NOUT; ++o) {
                     f32x4 g = SREG ? gwoacc[o] : (f32x4)(0.f);
@@ -1099,9 +1123,16 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_coop(NetDesc nd, const fl
             }
         }
         // ---- hidden -> hidden maps j = NHH .. 1 ---------------------------------------------------------------------------
+        f32x4 zsave[RES ? C : 1];                                  // RES: own slice of zbar of the last even layer (a block's second map)
 #pragma unroll
         for (int j = NHH; j >= 1; --j) {
             if constexpr (!WREG) __builtin_amdgcn_sched_barrier(0);
+            if constexpr (RES) {
+                if ((j & 1) == 0) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) zsave[c] = zb[c];
+                }
+            }
             if constexpr (SREG) dbacc[j - 1] += zb[0];             // bias gradient of map j, own slice
             else {
                 const float z0[4] = {zb[0][0], zb[0][1], zb[0][2], zb[0][3]};
@@ -1197,8 +1228,14 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_coop(NetDesc nd, const fl
             if constexpr (H <= 64) __builtin_amdgcn_s_setprio(GPE_COOP_PRIO_P);
             if constexpr (!WREG) __builtin_amdgcn_sched_barrier(0);      // keep the phases' live ranges apart (256-register budget)
             // recompute X of layer j-1 (own slice), activation adjoint -> z of layer j-1, X^T into the shared buffer
+            if constexpr (RES) {
+                if ((j & 1) == 1 && j + 1 <= NHH) {                // abar of a block input: + zbar of the block's second map (the skip)
+#pragma unroll
+                    for (int c = 0; c < C; ++c) acc[c] += zsave[c];
+                }
+            }
             f32x4 xa[C];
-            act_from_stored<D, E>(st[0], st + 1, st + 1 + D, shift, xa);
+            act_from_stored<D, E>(st[0], st + 1, st + 1 + D, (RES && j - 1 >= 1) ? 0.f : shift, xa);
             act_adjoint<D, E>(st[0], st + 1, st + 1 + D, acc, zb);
 #pragma unroll
             for (int c = 0; c < C; ++c)

@@ -111,7 +111,12 @@ CASES = {
                                  w_reg_f=1.0, w_reg_lam=1.0, dx=1.0), 1, True),
     # residual-block networks (refine/box_to_gaussian_pinn_simulation.py:52-63,100-130): generic set
     "1d_residual_64x2blocks": (dict(layers=[1, 64, 64, 64, 1], net_kind=go.NET_RESIDUAL, activation=1, kinetic_coeff=1.0,
-                                    potential=go.POT_GAUSSIAN, pot_a=0.5, gamma=3.0, p=4, base_mode=1, perturb_scale=0.05, dx=0.03), 333, False),
+                                    potential=go.POT_GAUSSIAN, pot_a=0.5, gamma=3.0, p=4, base_mode=1, perturb_scale=0.05, dx=0.03), 333, True),
+    # (round 4: one or two residual blocks of width 32 / 64 run on the cooperative whole-network kernels, <..., RES>)
+    "1d_residual_64x1block": (dict(layers=[1, 64, 64, 1], net_kind=go.NET_RESIDUAL, activation=1, kinetic_coeff=1.0, gamma=2.0, base_mode=0,
+                                   perturb_scale=0.05, dx=0.03), 200, True),
+    "2d_residual_64x2blocks": (dict(layers=[2, 64, 64, 64, 1], net_kind=go.NET_RESIDUAL, gamma=20.0, dx=0.01), 300, True),
+    "3d_residual_32x2blocks": (dict(layers=[3, 32, 32, 32, 1], net_kind=go.NET_RESIDUAL, gamma=5.0, omega=(1.0, 1.4, 2.0), dx=0.01), 130, True),
     "2d_residual_128x3blocks": (dict(layers=[2, 128, 128, 128, 128, 1], net_kind=go.NET_RESIDUAL, gamma=20.0, dx=0.01), 300, False),
     # four and five hidden -> hidden maps at H <= 64 (round 4: on the cooperative whole-network kernels; the per-wave-tile kernels hold three)
     "2d_64x5_four_maps": (dict(layers=[2, 64, 64, 64, 64, 64, 1], gamma=100.0, dx=0.01), 777, True),
@@ -1149,13 +1154,23 @@ def test_fused_and_generic_agree_at_per_gpu_size(name):
 
 
 # ---- row f3: residual-block network flavour against numbers from the reference's own class (tests/golden/make_golden_box2gauss.py) ----
+@pytest.mark.parametrize("path", ["generic", "fused"])
 @pytest.mark.parametrize("name", ["fx_box2gauss_m0_g0.npz", "fx_box2gauss_m1_g5_p4.npz"])
-def test_golden_box_to_gaussian_residual_network(name):
+def test_golden_box_to_gaussian_residual_network(name, path):
+    """(round 4: the residual network runs on the cooperative whole-network kernels by default -- `fused` -- and on the generic set when asked)"""
     fx = H.load_fx(name)
     pb = H.problem_from_box2gauss(fx)
     xb = np.array([[float(fx["lb"])], [float(fx["ub"])]])
-    eng = make_engine(pb, fx["flat0"], fx["x"], xb)
-    assert eng.active_path == gpe_pinn.PATH_GENERIC
+    if path == "fused" and len(pb.layers) - 3 > 2:          # three blocks: no whole-network kernel (one or two), the forced path says so
+        with pytest.raises(ValueError):
+            make_engine(pb, fx["flat0"], fx["x"], xb, path=PATHS[path])
+        return
+    eng = make_engine(pb, fx["flat0"], fx["x"], xb, path=PATHS[path])
+    assert eng.active_path == PATHS[path]
+    if path == "fused":
+        auto = make_engine(pb, fx["flat0"], fx["x"], xb)
+        assert auto.active_path == gpe_pinn.PATH_FUSED and "coop" in auto.active_kernels["bwd"]
+        auto.close()
     fwd = eng.forward(torch.as_tensor(fx["x"], device="cuda")).cpu().numpy()
     assert H.rel_err(fwd, fx["forward_out"]) < 1e-5
     jets = eng.forward_jets(torch.as_tensor(fx["x"], device="cuda")).cpu().numpy()
