@@ -521,7 +521,7 @@ def main():
         if tj:
             ks = tj.get("kernels", {})
             if "w_bwd_map" in kernels["bwd"]:       # the reverse pass is several launches: bytes of ONE pass = sum over its launches
-                fwd_n = max([v["dispatches"] for k, v in ks.items() if "w_forward" in k] or [0])
+                fwd_n = max([v["dispatches"] for k, v in ks.items() if "w_forward" in k or "f_forward" in k] or [0])      # (H = 128 in 1D / 2D: f_forward_coop)
                 tot = sum(v["hbm_bytes_per_point"] * v["dispatches"] for k, v in ks.items() if "w_bwd" in k)
                 if fwd_n:
                     traffic = tot / fwd_n * n_rows
