@@ -722,12 +722,14 @@ static bool plain_terms(const gpe_engine* e) {
 // the head too, k_head_pde is not launched and the step sums are added in a fixed order
 // problem class whose head the forward kernels can run (head_point_real): real psi, no orthogonality / Riesz / symmetry terms
 static bool head_class(gpe_engine* e) {
-    return e->fuse_head && e->head_slots && e->path == GPE_PATH_FUSED && !e->wide && e->H <= 64 && e->nd.n_lin - 2 <= 3 && e->cfg.net_kind == GPE_NET_MLP && e->nd.n_out == 1 && !e->cfg.complex_psi &&
+    return e->fuse_head && e->head_slots && e->path == GPE_PATH_FUSED && !e->wide && e->H <= 64 && e->nd.n_out == 1 && !e->cfg.complex_psi &&
            e->ph.n_orth == 0 && plain_terms(e) && e->cfg.w_sym == 0.f && e->main.C >= 3 && e->main.n > 0;
 }
 // ... by the cooperative forward kernel (small batches; the reverse kernel forms the seeds and adds the triples)
 static bool head_fusable_coop(gpe_engine* e) {
-    return head_class(e) && e->main.n <= e->fuse_head_max && fwd_coop(e, e->main) && seed_in_reverse(e) && fused_grid(e, e->main.n, 1, 2) <= HEAD_SLOTS;
+    // (four / five maps and residual blocks have no seed-forming reverse kernel: k_seed_pde adds their triples, as it does for large batches)
+    const bool deep = e->nd.n_lin - 2 > 3 || e->cfg.net_kind == GPE_NET_RESIDUAL;
+    return head_class(e) && e->main.n <= e->fuse_head_max && fwd_coop(e, e->main) && (seed_in_reverse(e) || deep) && fused_grid(e, e->main.n, 1, 2) <= HEAD_SLOTS;
 }
 // ... by the per-wave-tile forward kernel (large batches; k_seed_pde, or the seed-forming reverse kernel, adds the triples)
 static bool head_fusable_tile(gpe_engine* e) {
@@ -742,10 +744,17 @@ static void launch_fcoop_no(gpe_engine* e, Batch& b, unsigned grid, size_t lds, 
         if (e->fh_now && &b == &e->main) {
             const HeadArgs ha{e->ph, e->base_norm, b.V, (const float* const*)e->orth_dev, e->bc_target, b.u, b.Hu, b.Ob, e->n_pde, b.ld, e->head_slots};
             const size_t ldsh = lds + (size_t)CC * 16 * sizeof(float);
+            if (e->cfg.net_kind == GPE_NET_RESIDUAL) {
+                if (e->nd.n_lin - 2 == 2) hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, 1, 2, true, true>), dim3(grid), dim3(HH * 4), ldsh, e->stream, CARGS, ha);
+                else hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, 1, 4, true, true>), dim3(grid), dim3(HH * 4), ldsh, e->stream, CARGS, ha);
+                return;
+            }
             switch (e->nd.n_lin - 2) {
                 case 1: hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, 1, 1, true>), dim3(grid), dim3(HH * 4), ldsh, e->stream, CARGS, ha); break;
                 case 2: hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, 1, 2, true>), dim3(grid), dim3(HH * 4), ldsh, e->stream, CARGS, ha); break;
-                default: hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, 1, 3, true>), dim3(grid), dim3(HH * 4), ldsh, e->stream, CARGS, ha); break;
+                case 3: hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, 1, 3, true>), dim3(grid), dim3(HH * 4), ldsh, e->stream, CARGS, ha); break;
+                case 4: hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, 1, 4, true>), dim3(grid), dim3(HH * 4), ldsh, e->stream, CARGS, ha); break;
+                default: hipLaunchKernelGGL((f_forward_coop<HH, CC, EE, 1, 5, true>), dim3(grid), dim3(HH * 4), ldsh, e->stream, CARGS, ha); break;
             }
             return;
         }

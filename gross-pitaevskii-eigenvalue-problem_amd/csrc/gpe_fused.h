@@ -799,7 +799,7 @@ __global__ __launch_bounds__(H * 4, 2) void f_forward_coop(NetDesc nd, const flo
                                                            float* __restrict__ stored, float* __restrict__ O, int64_t N,
                                                            int64_t ld, int store_acts, HeadArgs ha) {
     static_assert(!HEADF || NOUT == 1, "head in the forward kernel: real psi");
-    static_assert(!RES || ((NHH & 1) == 0 && !HEADF && H <= 64), "residual blocks: two maps each");
+    static_assert(!RES || ((NHH & 1) == 0 && H <= 64), "residual blocks: two maps each");
     constexpr int D = C - 1 - E, NT = H / 16, NTHR = 64 * NT;
     constexpr int L = NHH + 1;
     extern __shared__ __attribute__((aligned(16))) float lds_c[];
