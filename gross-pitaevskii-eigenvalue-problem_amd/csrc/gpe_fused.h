@@ -42,6 +42,9 @@
 #define GPE_COOP_PRIO 1      // s_setprio level of the product phases of f_backward_coop (H <= 64); 0 switches it off
 #endif
 #ifndef GPE_FCOOP_SWP
+#ifndef GPE_COOP_WREG_MAX
+#define GPE_COOP_WREG_MAX 5  // f_backward_coop, H <= 64: most hidden->hidden maps whose W^T slices stay in registers (more: streamed from L2 as for H = 128)
+#endif
 #define GPE_FCOOP_SWP 0      // f_forward_coop<128>: B fragments of K tile kt+1 requested before the products of tile kt
 #endif
 #ifndef GPE_PIPE_G0REG
@@ -1014,7 +1017,7 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_coop(NetDesc nd, const fl
     // H <= 64: register-resident for the whole kernel.  H = 128: streamed from L2 in chunks of NTC tiles, the first chunk
     // requested before the barrier that precedes its use.
     static_assert(!B6 || H <= 64, "split-bf16 adjoint products: H <= 64");
-    constexpr bool WREG = (H <= 64) && !B6;
+    constexpr bool WREG = (H <= 64) && !B6 && NHH <= GPE_COOP_WREG_MAX;
     constexpr int NTC = WREG ? NT : 4;
     const float* wbase = WpkT;
     // B6: W^T pieces [map][piece][kt][kb][lane] x 16 B, behind WpkT and the forward pieces
