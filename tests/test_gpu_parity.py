@@ -637,6 +637,13 @@ def test_side_stream_and_graph_replay_change_nothing(kw, N):
     (dict(layers=[2, 128, 128, 128, 1], gamma=50.0, dx=0.01), 777,
      [{"GPE_WIDE": "0", "GPE_COOP128": "1", "GPE_COOP_FWD128": "1"}, {"GPE_WIDE": "0", "GPE_COOP128": "0", "GPE_COOP_FWD128": "0"},
       {"GPE_WIDE": "0", "GPE_COOP128": "1", "GPE_COOP_FWD128": "0"}, {"GPE_WIDE_MIN_TILES": "0"}, {"GPE_WIDE": "1", "GPE_WIDE_MIN_TILES": "0"}]),
+    # residual blocks: cooperative whole-network kernels with the skip connection, head in the forward kernel or in its own launch
+    (dict(layers=[1, 64, 64, 64, 1], net_kind=go.NET_RESIDUAL, activation=1, kinetic_coeff=1.0, potential=go.POT_GAUSSIAN, pot_a=0.5, gamma=3.0,
+          base_mode=0, perturb_scale=0.05, dx=0.01), 1000,
+     [{}, {"GPE_FUSE_HEAD": "0"}]),
+    # five hidden -> hidden maps at H = 64: cooperative kernels (default) against the unstaged per-wave-tile pair (GPE_COOP=0)
+    (dict(layers=[2, 64, 64, 64, 64, 64, 64, 1], gamma=20.0, dx=0.01), 900,
+     [{}, {"GPE_FUSE_HEAD": "0"}, {"GPE_COOP": "0"}]),
 ])
 def test_kernel_variants_agree(kw, N, envs):
     """The fused path has several kernels for the same two primitives -- cooperative (a workgroup per tile), per-wave-tile with
@@ -671,7 +678,7 @@ def test_kernel_variants_agree(kw, N, envs):
     # every row ran a different kernel pair -- unless the suite itself runs under a forced switch (e.g. GPE_FWD_B6=1 GPE_BWD_B6=1 to
     # put the split-bf16 kernels through every test), which makes some rows coincide: then at least two distinct pairs
     import os
-    forced = [k for k in ("GPE_FWD_B6", "GPE_BWD_B6", "GPE_PIPE", "GPE_COOP", "GPE_WIDE", "GPE_WIDE_MIN_TILES", "GPE_COOP_FWD_MAX_TILES", "GPE_STAGE_MIN_TILES", "GPE_FUSE_SEED", "GPE_FUSE_HEAD")
+    forced = [k for k in ("GPE_FWD_B6", "GPE_BWD_B6", "GPE_PIPE", "GPE_COOP", "GPE_WIDE", "GPE_WIDE_MIN_TILES", "GPE_RES_FUSED", "GPE_COOP_FWD_MAX_TILES", "GPE_STAGE_MIN_TILES", "GPE_FUSE_SEED", "GPE_FUSE_HEAD")
               if k in os.environ]
     if forced:
         assert len(seen) >= 2, f"forced {forced}: switches selected only {sorted(seen)}"
