@@ -1346,3 +1346,14 @@ def test_multi_tile_wide_forward_kernel_matches_oracle():
                         "-k", "test_step_matches_oracle and 128 and fused"], capture_output=True, text=True, timeout=600, cwd=root, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def test_randomised_parity_sweep():
+    """tools/fuzz_parity.py, 120 random problem descriptions (dimension, hidden widths native / odd / ragged / above 256, depth, activation, residual
+    blocks, complex psi, Riesz forms, energy-functional lambda, regularisers, symmetry, 7 .. 3 000 points) through whatever kernel set gpe_create
+    picks, against the fp64 oracle: loss 2e-4, mu 5e-5, gradient 1e-4.  (1 200 cases from one point up: profiles/r04/fuzz_parity.txt.)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "120", "3", "7"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1500:]
+
