@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep: engine (kernel set as gpe_create picks it: fused / wide / padded / residual / generic) against the fp64 oracle on
 random problem descriptions -- dimensions, hidden widths (native, odd, ragged), depth, activation, residual blocks, loss terms (Riesz forms,
-energy-functional lambda, regularisers, symmetry), batch sizes down to one point.  usage: python tools/fuzz_parity.py [cases] [seed] [smallest N]"""
+energy-functional lambda, regularisers, symmetry), batch sizes down to one point.  usage: python tools/fuzz_parity.py [cases] [seed] [smallest N] [steps]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -14,6 +14,7 @@ from tests import helpers as H
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 min_n = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+n_steps = int(sys.argv[4]) if len(sys.argv) > 4 else 1          # > 1: also follow the fp64 oracle's optimiser for that many steps (loss per step)
 bad = 0
 t0 = time.time()
 for it in range(cases):
@@ -61,6 +62,24 @@ for it in range(cases):
     xb = (np.array([[-5.0], [5.0]]) if d == 1 else rng.uniform(-3, 3, (5, d))).astype(np.float32)
     flat = (rng.normal(0, 1, go.param_count(layers, kw["net_kind"])) * scale).astype(np.float32)
     pb = go.Problem(**kw)
+    only = os.environ.get("FUZZ_ONLY")
+    if only is not None and int(only) != it:
+        continue
+    if only is not None:          # one case in detail: per-step losses of the oracle, the engine as picked, and the generic set on the network as given
+        st = go.OptState(lr0=1e-3)
+        _, tr = go.train_steps(pb, st, flat.astype(np.float64), x.astype(np.float64), n_steps, xb.astype(np.float64), dtype=np.float64)
+        rows = {"oracle": [t["loss"] for t in tr]}
+        for name, over in (("auto", {}), ("generic", dict(path=gpe_pinn.PATH_GENERIC))):
+            eng = gpe_pinn.Engine(cfg_from_problem(pb, **over))
+            eng.set_params(flat); eng.bind_points(torch.as_tensor(x, device="cuda")); eng.bind_boundary(torch.as_tensor(xb, device="cuda"))
+            rows[name] = [eng.step()["loss"] for _ in range(n_steps)]
+            rows[name + "_gn"] = eng.read_scalars()["grad_norm"]
+            eng.close()
+        print(layers, kw)
+        for k in range(n_steps):
+            print(k, " ".join(f"{nm} {rows[nm][k]:.9g}" for nm in ("oracle", "auto", "generic")))
+        print("grad norms", rows["auto_gn"], rows["generic_gn"], "oracle gn", [t["grad_norm"] for t in tr])
+        sys.exit(0)
     try:
         osc, ograd, _ = go.full_loss_and_grad(pb, flat.astype(np.float64), x.astype(np.float64), xb.astype(np.float64))
         eng = gpe_pinn.Engine(cfg_from_problem(pb))
@@ -70,18 +89,24 @@ for it in range(cases):
         kern = eng.active_kernels
         sc = eng.step()
         g = eng.get_grad()
+        traj = 0.0
+        if n_steps > 1:
+            st = go.OptState(lr0=1e-3)
+            _, tr = go.train_steps(pb, st, flat.astype(np.float64), x.astype(np.float64), n_steps, xb.astype(np.float64), dtype=np.float64)
+            losses = [sc["loss"]] + [eng.step()["loss"] for _ in range(n_steps - 1)]
+            traj = max(abs(a - t["loss"]) / max(abs(t["loss"]), 1e-30) / (1 + k) for k, (a, t) in enumerate(zip(losses, tr)))
         eng.close()
         f = 10.0 if N < 4 else 1.0
         el = abs(sc["loss"] - osc["loss"]) / max(abs(osc["loss"]), 1e-30)
         em = abs(sc["mu"] - osc["mu"]) / max(abs(osc["mu"]), 1e-6)
         eg = H.rel_err(g, ograd)
-        ok = el < f * 2e-4 and em < f * 5e-5 and eg < f * 1e-4 and np.isfinite(el + em + eg)
+        ok = el < f * 2e-4 and em < f * 5e-5 and eg < f * 1e-4 and traj < f * 1e-3 and np.isfinite(el + em + eg + traj)
         tag = "ok " if ok else "BAD"
     except Exception as ex:           # noqa: BLE001 -- the sweep reports, it does not stop
-        ok, tag, el, em, eg, kern = False, "EXC", float("nan"), float("nan"), float("nan"), {"fwd": str(ex)[:80], "bwd": ""}
+        ok, tag, el, em, eg, traj, kern = False, "EXC", float("nan"), float("nan"), float("nan"), float("nan"), {"fwd": str(ex)[:80], "bwd": ""}
     bad += 0 if ok else 1
     if not ok or it % 10 == 0:
         print(f"{tag} #{it:3d} N={N:5d} {layers} act={act} res={int(residual)} {{{', '.join(f'{k}={v}' for k, v in kw.items() if k not in ('layers', 'activation', 'net_kind', 'dx', 'kinetic_coeff'))}}} "
-              f"loss {el:.1e} mu {em:.1e} grad {eg:.1e}  {kern['fwd'][:34]} / {kern['bwd'][:30]}", flush=True)
+              f"loss {el:.1e} mu {em:.1e} grad {eg:.1e} traj {traj:.1e}  {kern['fwd'][:34]} / {kern['bwd'][:30]}", flush=True)
 print(f"{cases} cases, {bad} failures, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
