@@ -15,6 +15,8 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 min_n = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 n_steps = int(sys.argv[4]) if len(sys.argv) > 4 else 1          # > 1: also follow the fp64 oracle's optimiser for that many steps (loss per step)
+dp_mode = len(sys.argv) > 5 and sys.argv[5] == "dp"             # also: the step of TWO engines on the two halves of the points (world_size = 2, exchange
+                                                                # buffers summed by hand as the all-reduces would) against the single engine's
 bad = 0
 t0 = time.time()
 for it in range(cases):
@@ -48,6 +50,10 @@ for it in range(cases):
             kw.update(w_reg_f=0.5)
         if d == 1 and rng.random() < 0.5:
             kw.update(base_mode=int(rng.integers(0, 4)), perturb_scale=float(rng.choice([1.0, 0.05])))
+            if rng.random() < 0.3:          # box base + hard boundary factor (refine/box_pinn_simulation.py)
+                kw.update(base_kind=go.BASE_BOX, envelope=go.ENV_SIN, box_L=10.0, env_L=10.0)
+        if d == 1 and rng.random() < 0.4:
+            kw.update(potential=int(rng.choice([go.POT_GAUSSIAN, go.POT_PERIODIC, go.POT_NONE])), pot_a=0.5)
         if rng.random() < 0.15:
             kw.update(w_sym=5.0, sym_sign=float(rng.choice([1.0, -1.0])))
     if d == 3:
@@ -96,6 +102,30 @@ for it in range(cases):
             losses = [sc["loss"]] + [eng.step()["loss"] for _ in range(n_steps - 1)]
             traj = max(abs(a - t["loss"]) / max(abs(t["loss"]), 1e-30) / (1 + k) for k, (a, t) in enumerate(zip(losses, tr)))
         eng.close()
+        dpe = 0.0
+        if dp_mode and N >= 2:
+            import dataclasses
+            pbn = dataclasses.replace(pb, n_global=N)
+            lo = N // 2
+            engs = []
+            for xs in (x[:lo], x[lo:]):
+                e2 = gpe_pinn.Engine(cfg_from_problem(pbn, world_size=2))
+                e2.set_params(flat); e2.bind_points(torch.as_tensor(xs, device="cuda")); e2.bind_boundary(torch.as_tensor(xb, device="cuda"))
+                engs.append(e2)
+            for e2 in engs: e2.step_begin()
+            tot = engs[0].exchange_sums + engs[1].exchange_sums
+            for e2 in engs:
+                e2.exchange_sums.copy_(tot); e2.step_backward()
+            gt = engs[0].exchange_grad + engs[1].exchange_grad
+            for e2 in engs:
+                e2.exchange_grad.copy_(gt); e2.step_update()
+            s2 = engs[0].read_scalars()
+            dpe = max(abs(s2["loss"] - sc["loss"]) / max(abs(sc["loss"]), 1e-30), abs(s2["mu"] - sc["mu"]) / max(abs(sc["mu"]), 1e-6),
+                      H.rel_err(engs[0].get_grad(), g) / 5.0)
+            same = np.array_equal(engs[0].get_params(), engs[1].get_params())
+            for e2 in engs: e2.close()
+            if not same: dpe = float("inf")
+        traj = max(traj, 50.0 * dpe)          # (reported in the same column: the two-rank step within 2e-5 of the single engine's, replicas bit-identical)
         f = 10.0 if N < 4 else 1.0
         el = abs(sc["loss"] - osc["loss"]) / max(abs(osc["loss"]), 1e-30)
         em = abs(sc["mu"] - osc["mu"]) / max(abs(osc["mu"]), 1e-6)
