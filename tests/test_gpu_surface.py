@@ -337,7 +337,8 @@ def test_rotating_trap_vortex_lattice_against_the_grid_solver(tmp_path):
     1.6e-5 .. 2.7e-4, i.e. the same state to delta ~ 1e-2, and |mu - mu_ref| = 3.0e-4, 7.5e-4, 1.2e-3, 4.3e-5: one of five outside
     1e-3 although its energy (2.4e-4) is as good as the others'.  It is not the norm drift either: mu of the NORMALISED state of that run
     (from mu, E and int |psi|^2) is 1.3e-3 off.  1e-3 on mu would need delta ~ 3e-3, i.e. E to ~1e-5 (reached by one run), which this
-    162-second schedule does not deliver reliably; 2e-3 is what it does."""
+    162-second schedule does not deliver reliably; 2e-3 is what it does.  (Round-4 final build, seeds 0 / 1 / 2: 4.6e-4, 9.1e-4, 3.1e-4 --
+    profiles/r04/accuracy_cfg4_2d_6x128_rot*.json -- seven of the eight recorded runs within 1e-3.)"""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = str(tmp_path / "acc4.json")
