@@ -358,9 +358,7 @@ __global__ __launch_bounds__(1024) void k_reduce_update(const float* __restrict_
     __shared__ int s_last;
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + lane;
-    float s = 0.f;
-    if (i < P)
-        for (int b = g; b < nslab; b += 16) s += gslab[(size_t)b * Ppad + i];
+    const float s = i < P ? slab_column_sum(gslab, nslab, Ppad, i, g) : 0.f;
     red[g][lane] = s;
     __syncthreads();
     if (g == 0 && i < P) {

@@ -1780,6 +1780,23 @@ __global__ __launch_bounds__(H * 4, 2) void f_backward_pipe(NetDesc nd, const fl
     }
 }
 
+// One thread's share of a slab column: gslab[g][i] + gslab[g + 16][i] + ... added IN THAT ORDER.  Eight loads are requested before the
+// first add (round 4: the plain loop compiled to load -> s_waitcnt vmcnt(0) -> add -> branch, one L2 / HBM round trip per slab, 32 in a
+// row at 512 slabs -- the whole 11 us of the reduction at BASELINE configs[1]); the sequence of additions, and with it every bit of
+// the sum, is the plain loop's.
+__device__ __forceinline__ float slab_column_sum(const float* __restrict__ gslab, int nslab, int Ppad, int i, int g) {
+    const float* p = gslab + (size_t)g * Ppad + i;
+    const size_t st = (size_t)16 * Ppad;
+    float s = 0.f;
+    int b = g;
+    for (; b + 16 * 7 < nslab; b += 16 * 8, p += 8 * st) {
+        const float v0 = p[0], v1 = p[st], v2 = p[2 * st], v3 = p[3 * st], v4 = p[4 * st], v5 = p[5 * st], v6 = p[6 * st], v7 = p[7 * st];
+        s += v0; s += v1; s += v2; s += v3; s += v4; s += v5; s += v6; s += v7;
+    }
+    for (; b < nslab; b += 16, p += st) s += *p;
+    return s;
+}
+
 // grad[i] (+)= sum_b gslab[b][i] (+ add[i]).  Block = 64 parameters x 16 slab groups (1024 threads); fixed summation order, so the
 // slab sum is deterministic for a given grid.  The last reduction of a step also adds the boundary-batch gradient `add` and
 // writes the exchange tail (tail_dsc != NULL): grad[P + GT_SUM_R2], grad[P + GT_MSE_SE2].
@@ -1789,9 +1806,7 @@ __global__ __launch_bounds__(1024) void k_grad_reduce(const float* __restrict__ 
     __shared__ float red[16][64];
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + lane;
-    float s = 0.f;
-    if (i < P)
-        for (int b = g; b < nslab; b += 16) s += gslab[(size_t)b * Ppad + i];
+    const float s = i < P ? slab_column_sum(gslab, nslab, Ppad, i, g) : 0.f;
     red[g][lane] = s;
     __syncthreads();
     if (g == 0 && i < P) {
