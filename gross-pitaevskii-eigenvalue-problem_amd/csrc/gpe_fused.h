@@ -150,9 +150,7 @@ __global__ __launch_bounds__(256, ((C <= 5 && H <= 64) ? GPE_FWD_WAVES : 1)) voi
     stage_layer0<H>(w0s, theta, nd, 256);
     const buf_t rW = buf_make(Wpk, (unsigned)((L - 1) * H * H * 4));
     if constexpr (WLDS) {
-        const int n4 = (L - 1) * H * H / 4;
-        for (int i = threadIdx.x; i < n4; i += 256)
-            reinterpret_cast<f32x4*>(lds_w)[i] = reinterpret_cast<const f32x4*>(Wpk)[i];
+        stage_copy16(reinterpret_cast<f32x4*>(lds_w), reinterpret_cast<const f32x4*>(Wpk), (L - 1) * H * H / 4, (int)threadIdx.x, 256);
     }
     __syncthreads();
 
@@ -329,8 +327,7 @@ __global__ __launch_bounds__(256, 2) void f_forward_b6(NetDesc nd, const float* 
     const u32x4* lds_w = reinterpret_cast<const u32x4*>(lds_f + ((small_count(nd, H) + 3) & ~3));
     if constexpr (WLDS) {
         u32x4* dst = reinterpret_cast<u32x4*>(lds_f + ((small_count(nd, H) + 3) & ~3));
-        const int n16 = (L - 1) * 3 * H * H * 2 / 16;
-        for (int i = threadIdx.x; i < n16; i += 256) dst[i] = reinterpret_cast<const u32x4*>(W6)[i];
+        stage_copy16(dst, reinterpret_cast<const u32x4*>(W6), (L - 1) * 3 * H * H * 2 / 16, (int)threadIdx.x, 256);
     }
     __syncthreads();
 
@@ -514,9 +511,7 @@ __global__ __launch_bounds__((NHH > 0 ? 256 : (WLDS ? 512 : 256)), ((NHH > 0 || 
     else { for (int i = threadIdx.x; i < Ppad + 4 * H; i += NTHR) gacc[i] = 0.f; }      // gacc and g0 are contiguous
     stage_layer0<H>(w0s, theta, nd, NTHR);
     if constexpr (WLDS) {
-        const int n4 = (L - 1) * H * H / 4;
-        for (int i = threadIdx.x; i < n4; i += NTHR)
-            reinterpret_cast<f32x4*>(lds_w)[i] = reinterpret_cast<const f32x4*>(WpkT)[i];
+        stage_copy16(reinterpret_cast<f32x4*>(lds_w), reinterpret_cast<const f32x4*>(WpkT), (L - 1) * H * H / 4, (int)threadIdx.x, NTHR);
     }
     __syncthreads();
 
@@ -815,13 +810,13 @@ __global__ __launch_bounds__(H * 4, 2) void f_forward_coop(NetDesc nd, const flo
     const int dim = nd.dim;
     const float shift = nd.shift;
     const int64_t ntiles = (N + 15) >> 4;
-    stage_layer0<H>(w0s, theta, nd, NTHR);
     f32x4 wreg[NHH][NT];                                        // rows 16w..16w+15 of W_j, K tile kt
 #pragma unroll
     for (int a = 0; a < NHH; ++a)
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
             wreg[a][kt] = *reinterpret_cast<const f32x4*>(&Wpk[(size_t)a * H * H + ((w * NT + kt) * 64 + lane) * 4]);
+    stage_layer0<H>(w0s, theta, nd, NTHR);                      // (behind the weight requests: its two round trips run beside theirs)
     __syncthreads();
     const float* Wo = w0s + (4 + L - 1) * H;
     const float* bo = w0s + (4 + L - 1 + NOUT) * H;

@@ -124,16 +124,54 @@ template <int H>
 GPE_DEV void stage_layer0(float* w0s, const float* __restrict__ theta, const NetDesc& nd, int nthr, int tix = -1) {
     const int L = nd.n_lin - 1;
     if (tix < 0) tix = threadIdx.x;               // (tix: thread index within the group of nthr threads that fills this copy)
-    for (int i = tix; i < 4 * H; i += nthr) {
+    // The first pass of all four copy loops is requested TOGETHER, then written (round 4): as four loops in a row, each with its
+    // offset-table load -> parameter load -> s_waitcnt vmcnt(0) -> ds_write, the prologue of every fused kernel was a chain of
+    // eight L2 round trips -- 3-4 us before a workgroup's first tile, a tenth of a kernel at the reference's batch sizes.
+    const int n1 = 4 * H, n2 = (L - 1) * H, n3 = nd.n_out * H, n4 = nd.n_out;
+    float v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
+    if (tix < n1) {
+        const int k = tix / H, n = tix % H;
+        if (k == 3) v1 = theta[nd.offB[0] + n];
+        else if (k < nd.dim) v1 = theta[nd.offW[0] + n * nd.dim + k];
+    }
+    if (tix < n2) v2 = theta[nd.offB[1 + tix / H] + tix % H];
+    if (tix < n3) v3 = theta[nd.offW[L] + tix];
+    if (tix < n4) v4 = theta[nd.offB[L] + tix];
+    if (tix < n1) w0s[tix] = v1;
+    if (tix < n2) w0s[4 * H + tix] = v2;
+    if (tix < n3) w0s[(4 + L - 1) * H + tix] = v3;
+    if (tix < n4) w0s[(4 + L - 1 + nd.n_out) * H + tix] = v4;
+    for (int i = tix + nthr; i < n1; i += nthr) {
         const int k = i / H, n = i % H;
         float v;
         if (k == 3) v = theta[nd.offB[0] + n];
         else v = (k < nd.dim) ? theta[nd.offW[0] + n * nd.dim + k] : 0.f;
         w0s[i] = v;
     }
-    for (int i = tix; i < (L - 1) * H; i += nthr) w0s[4 * H + i] = theta[nd.offB[1 + i / H] + i % H];
-    for (int i = tix; i < nd.n_out * H; i += nthr) w0s[(4 + L - 1) * H + i] = theta[nd.offW[L] + i];
-    for (int i = tix; i < nd.n_out; i += nthr) w0s[(4 + L - 1 + nd.n_out) * H + i] = theta[nd.offB[L] + i];
+    for (int i = tix + nthr; i < n2; i += nthr) w0s[4 * H + i] = theta[nd.offB[1 + i / H] + i % H];
+    for (int i = tix + nthr; i < n3; i += nthr) w0s[(4 + L - 1) * H + i] = theta[nd.offW[L] + i];
+    for (int i = tix + nthr; i < n4; i += nthr) w0s[(4 + L - 1 + nd.n_out) * H + i] = theta[nd.offB[L] + i];
+}
+
+// global -> LDS copy of n16 16-byte elements by nthr threads: four loads per thread requested at once and the next four behind them
+// before the first four are written (round 4: the plain loop compiled to ONE dwordx4 load -> s_waitcnt vmcnt(0) -> ds_write_b128 per
+// pass, twelve L2 round trips in a row for three 64 x 64 maps).
+template <typename V4>
+GPE_DEV void stage_copy16(V4* __restrict__ dst, const V4* __restrict__ src, int n16, int tix, int nthr) {
+    int i = tix;
+    V4 c0, c1, c2, c3;
+    const bool have = i + 3 * nthr < n16;
+    if (have) { c0 = src[i]; c1 = src[i + nthr]; c2 = src[i + 2 * nthr]; c3 = src[i + 3 * nthr]; }
+    while (i + 3 * nthr < n16) {
+        const int j = i + 4 * nthr;
+        const bool more = j + 3 * nthr < n16;
+        V4 d0 = c0, d1 = c1, d2 = c2, d3 = c3;
+        if (more) { d0 = src[j]; d1 = src[j + nthr]; d2 = src[j + 2 * nthr]; d3 = src[j + 3 * nthr]; }
+        dst[i] = c0; dst[i + nthr] = c1; dst[i + 2 * nthr] = c2; dst[i + 3 * nthr] = c3;
+        c0 = d0; c1 = d1; c2 = d2; c3 = d3;
+        i = j;
+    }
+    for (; i < n16; i += nthr) dst[i] = src[i];
 }
 
 // stored-equivalent (t, z_k, z_kk) of hidden layer 0 for features 16nt+4q+r, recomputed from the point coordinates
